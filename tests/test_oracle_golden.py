@@ -1,0 +1,168 @@
+"""Pins oracle/ (the CPU restatement) against the golden vectors that
+tests/golden/make_golden.py produced by running the REFERENCE's own modules.
+CPU only; nothing here reads /root/reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmbert_oracle as O
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False))
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def wsum(sd):
+    return float(sum(v.double().abs().sum() for v in sd.values() if v.dtype.is_floating_point))
+
+
+def close(a, b, tol=2e-5, what=""):
+    a, b = t(a).double() if not isinstance(a, torch.Tensor) else a.double(), t(b).double()
+    err = (a - b).abs().max().item()
+    ref = max(1.0, b.abs().max().item())
+    assert err <= tol * ref, f"{what}: max err {err:.3e} (ref scale {ref:.3e})"
+
+
+def zero_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+
+
+def test_activations(golden_dir):
+    g = load(golden_dir, "act")
+    x = t(g["x"]).requires_grad_(True)
+    y = O.serf(x)
+    y.sum().backward()
+    close(y, g["serf"], 1e-6, "serf")
+    close(x.grad, g["dserf"], 1e-6, "dserf")
+    x2 = t(g["x"]).requires_grad_(True)
+    y2 = O.gelu(x2)
+    y2.sum().backward()
+    close(y2, g["gelu"], 1e-6, "gelu")
+    close(x2.grad, g["dgelu"], 1e-6, "dgelu")
+
+
+def test_bertlayer(golden_dir):
+    g = load(golden_dir, "bertlayer")
+    H, heads, L, B, T = [int(v) for v in g["dims"]]
+    torch.manual_seed(int(g["seed"]))
+    m = O.OracleBertLayer(H, heads, L, 0.3).eval()
+    assert abs(wsum(m.state_dict()) - float(g["wsum"])) < 1e-6 * float(g["wsum"]), "RNG drift"
+    x = t(g["x"]).requires_grad_(True)
+    mask = t(g["mask"])
+    h = x
+    for i in range(L):
+        h = m(h, mask, i)
+    close(h, g["y"], 1e-5, "y")
+    (h * t(g["gy"])).sum().backward()
+    close(x.grad, g["dx"], 1e-5, "dx")
+    for k, p in m.named_parameters():
+        ref = g["g_" + k.replace(".", "__")]
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        close(got, ref, 1e-5, k)
+    # quirk 2: norm2 never receives gradient
+    assert m.norm2.weight.grad is None
+
+
+def test_realformer(golden_dir):
+    g = load(golden_dir, "realformer")
+    emb_s, L, B, T = [int(v) for v in g["dims"]]
+    torch.manual_seed(int(g["seed"]))
+    m = torch.nn.Sequential(*[O.OracleResEncoderBlock(emb_s, 8) for _ in range(L)]).eval()
+    assert abs(wsum(m.state_dict()) - float(g["wsum"])) < 1e-6 * float(g["wsum"]), "RNG drift"
+    x = t(g["x"]).requires_grad_(True)
+    mask = t(g["mask"])
+    h, prev = x, None
+    for blk in m:
+        h, prev = blk(h, prev=prev, mask=mask)
+    close(h, g["y"], 2e-5, "y")
+    close(prev, g["prev"], 1e-6, "prev")
+    (h * t(g["gy"])).sum().backward()
+    close(x.grad, g["dx"], 2e-5, "dx")
+    for k, p in m.named_parameters():
+        close(p.grad, g["g_" + k.replace(".", "__")], 2e-5, k)
+
+
+def test_losses(golden_dir):
+    g = load(golden_dir, "losses")
+    lg = t(g["asl_logits"]).requires_grad_(True)
+    l = O.asl_single_label(lg, t(g["asl_target"]))
+    l.backward()
+    close(l, g["asl"], 1e-6, "asl")
+    close(lg.grad, g["asl_dlogits"], 1e-6, "asl grad")
+    f = t(g["sc_feat"]).requires_grad_(True)
+    l = O.supcon_simclr(f)
+    l.backward()
+    close(l, g["sc"], 1e-6, "supcon")
+    close(f.grad, g["sc_dfeat"], 1e-5, "supcon grad")
+    lg = t(g["mlm_logits"]).requires_grad_(True)
+    l, lp = O.mlm_loss(lg, t(g["mlm_target"]))
+    l.backward()
+    close(l, g["mlm"], 1e-6, "mlm")
+    close(lg.grad, g["mlm_dlogits"], 1e-6, "mlm grad")
+    pred, _, _ = O.mlm_accuracy(lp, t(g["mlm_target"]))
+    assert np.array_equal(pred.numpy(), g["mlm_pred"])  # index ops bit-exact
+
+
+@pytest.mark.parametrize("tag,tm,ds,supcon", [
+    ("model_tr_roco", "transformer", "roco", False),
+    ("model_rf_roco_supcon", "realformer", "roco", True),
+    ("model_tr_vqa", "transformer", "VQA-Med", False),
+    ("model_rf_vqa", "realformer", "VQA-Med", False),
+])
+def test_model(golden_dir, tag, tm, ds, supcon):
+    g = load(golden_dir, tag)
+    B, T, hw, V = [int(v) for v in g["dims"]]
+    kw = dict(transformer_model=tm, dataset=ds, hidden_size=768, n_layers=2, heads=12, hidden_dropout_prob=0.0,
+              vocab_size=V, resnet_layers=(1, 1, 1, 1), resnet_width=64, bert_max_pos=32)
+    if supcon:
+        kw["supcon"] = True
+    args = O.make_args(**kw)
+    torch.manual_seed(int(g["seed"]))
+    m = O.OracleModel(args)
+    assert abs(wsum(m.state_dict()) - float(g["wsum"])) < 1e-6 * float(g["wsum"]), "RNG drift"
+    zero_dropout(m)
+    m.train()
+    out = m(t(g["img"]), t(g["ids"]), t(g["seg"]), t(g["mask"]))
+    tgt = t(g["target"])
+    if ds == "roco":
+        logits = out[0] if supcon else out
+        loss, _ = O.mlm_loss(logits, tgt)
+        if supcon:
+            close(out[1], g["feat"], 2e-5, "feat")
+            loss = loss + O.supcon_simclr(O.split_feat(out[1], B // 2))
+    else:
+        logits = out[0]
+        assert out[1] == 0 and out[2] == 0
+        loss = O.asl_single_label(logits, tgt)
+    close(logits, g["logits"], 5e-5, "logits")
+    close(loss, g["loss"], 2e-5, "loss")
+    loss.backward()
+    sd = dict(m.named_parameters())
+    for k in g:
+        if not k.startswith("g_"):
+            continue
+        name = k[2:].replace("__", ".")
+        gr = sd[name].grad
+        if gr.numel() > 8192:
+            gr = gr.flatten()[:: max(1, gr.numel() // 4096)][:4096]
+        close(gr, g[k], 1e-4, name)
+    fp = {n: v for n, v in zip(g["grad_names"], g["grad_fp"])}
+    for name, p in sd.items():
+        s, a = fp[name]
+        if p.grad is None:
+            assert a == 0.0, name
+        else:
+            assert abs(float(p.grad.double().abs().sum()) - a) <= 2e-4 * max(a, 1e-6), name
+    # quirk 7: single-pass backbone with k-fold BN running-stat updates == 5 prefix passes
+    bsd = m.state_dict()
+    for k in g:
+        if k.startswith("b_"):
+            close(bsd[k[2:].replace("__", ".")].double(), g[k], 1e-5, k)
