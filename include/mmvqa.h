@@ -1,0 +1,241 @@
+/* mmvqa.h -- C ABI of the MI355X-native MMBERT hot path (libmmvqa_hip.so).
+ *
+ * The reference (DannielSilva/MM-VQA) has no FFI: its boundary is the Python object
+ * protocol  Model(args) / model(img, ids, seg, mask) / state_dict  (models/mmbert.py:129-167,
+ * pretrain/roco_utils.py:214-247, vqamed2019/utils.py:633-666).  This header is the native side of
+ * that boundary: plain pointers + sizes + a hipStream_t, no torch types.  Every entry point
+ *   - borrows raw DEVICE pointers (never allocates or frees caller memory),
+ *   - enqueues on the given stream and returns without synchronising,
+ *   - returns 0 on success or a negative code; mmvqa_last_error() gives the message.
+ * INTEGRATION.md shows the ctypes binding the Python shim uses.
+ *
+ * Layout conventions: activations are NHWC ("channels last") fp32; conv weights are
+ * [Cout][KH][KW][Cin]; linear weights [out][in]; ids/masks/labels int64.
+ */
+#ifndef MMVQA_H
+#define MMVQA_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mmvqa_stream_t; /* hipStream_t */
+
+#define MMVQA_ACT_NONE 0
+#define MMVQA_ACT_RELU 1
+#define MMVQA_ACT_GELU 2 /* models/transformer.py:7-8 */
+#define MMVQA_ACT_SERF 3 /* models/serf.py:23-24 */
+
+#define MMVQA_KIND_FWD 0   /* C[pix,co]      = sum X[pix@tap,ci] W[co,tap,ci]      */
+#define MMVQA_KIND_DGRAD 1 /* C[pix_in,ci]   = sum dZ[pix_out,co] W[co,tap,ci]     */
+#define MMVQA_KIND_WGRAD 2 /* C[co,(tap,ci)] = sum dZ[pix,co] X[pix@tap,ci]        */
+
+#define MMVQA_STAT_SLOTS 16
+
+/* Descriptor of one implicit-GEMM launch (see mm-vqa_amd/csrc/igemm.hip for the field semantics).
+ * Replaces: torch.nn.Conv2d / nn.Linear forward+backward as used by models/image_encoding.py:53-86,
+ * models/transformer.py:13-15,45-48, models/realformer.py:13-27, models/mmbert.py:133-148. */
+typedef struct mmvqa_gemm_desc {
+  int M, N, K;
+  int splitk;
+  int ktiles_per_split;
+  const float* A;
+  const float* A2;
+  const float* a_c0;
+  const float* a_c1;
+  const float* a_c2;
+  int a_pro;
+  int a_ld;
+  const float* B;
+  const float* b_c0;
+  const float* b_c1;
+  int b_pro;
+  int b_ld;
+  int b_tapstride;
+  int g_SH, g_SW, g_Cs, g_OH, g_OW, g_KH, g_KW, g_stride, g_pad;
+  int g_nchw;
+  float* C;
+  int c_ld;
+  int c_atomic;
+  float* Cpre;
+  const float* bias;
+  int act;
+  int dact;
+  const float* Pre;
+  int pre_ld;
+  float drop_p;
+  uint32_t drop_seed;
+  const float* R;
+  int r_ld;
+  int epi_mode;
+  int tap_HW;
+  float* tap_out;
+  const float* tap_dv;
+  const float* Mk;
+  int mk_ld;
+  const float* mk_s;
+  const float* mk_b;
+  double* stat1;
+  int stat_bwd;
+  const float* Z1;
+  int z1_ld;
+  const float* mean1;
+  const float* invstd1;
+  double* stat2;
+  const float* Z2;
+  int z2_ld;
+  const float* mean2;
+  const float* invstd2;
+  float* colsum;
+} mmvqa_gemm_desc;
+
+/* Fused attention (models/transformer.py:19-30 and models/realformer.py:30-45). */
+typedef struct mmvqa_attn_desc {
+  const float* q;
+  const float* k;
+  const float* v;
+  int row_stride, head_stride;
+  float* out;
+  int out_row_stride, out_head_stride;
+  const long long* mask;
+  int mask_on_query;
+  const float* prev_in;
+  float* prev_out;
+  float* probs;
+  int B, T, heads;
+  float sqrt_d;
+  float drop_p;
+  uint32_t seed;
+  const float* dout;
+  float* dq;
+  float* dk;
+  float* dv;
+  const float* dprev_in;
+  float* dprev_out;
+} mmvqa_attn_desc;
+
+/* Architecture of one Model(args) instance: the option surface of pretrain/roco_train.py:23-60,
+ * vqamed2019/train.py:32-79 that the hot path reads (SURVEY.md section 5 "Config"). */
+typedef struct mmvqa_model_desc {
+  int cnn;              /* 0 = resnet (torchvision layout), 1 = tf_efficientnetv2_m (timm features_only) */
+  int resnet_layers[4]; /* (3,8,36,3) = resnet152 */
+  int resnet_width;     /* 64 */
+  int effnet_depth_div; /* 1 = full depth; >1 divides stage repeats (tests) */
+  int encoder;          /* 0 = transformer (BertLayer pre-LN), 1 = realformer */
+  int hidden, heads, n_layers;
+  int emb_vocab, max_pos, type_vocab;
+  int num_vis;
+  int head_kind;        /* 0 = roco (per-token MLM logits), 1 = VQA-Med (mean-pooled logits) */
+  int n_classes;        /* width of classifier[2] */
+  int supcon, feat_dim;
+  int use_relu;
+  float p_drop;         /* --hidden_dropout_prob (BertLayer attention + residual dropouts) */
+  float p_emb_drop;     /* BertEmbeddings dropout (0.1) */
+  float p_rf_drop;      /* RealFormer dp1/dp2 (0.1) */
+} mmvqa_model_desc;
+
+typedef struct mmvqa_engine mmvqa_engine;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int mmvqa_version(void);
+const char* mmvqa_last_error(void);
+size_t mmvqa_sizeof_gemm_desc(void);
+size_t mmvqa_sizeof_attn_desc(void);
+size_t mmvqa_sizeof_model_desc(void);
+
+/* ---- op level (each is what one torch op of the reference's hot path lowers to) ------------ */
+/* kind: MMVQA_KIND_*; nchw: 1 only for the 7x7 stem (NCHW image source); tile: 0 auto */
+int mmvqa_igemm(const mmvqa_gemm_desc* d, int kind, int nchw, int tile, mmvqa_stream_t s);
+int mmvqa_attention(const mmvqa_attn_desc* d, int head_dim, int backward, mmvqa_stream_t s);
+
+/* BatchNorm2d (train: batch stats + running update repeated `reps` times; eval: running stats) */
+int mmvqa_bn_coef_fwd(mmvqa_stream_t s, const double* stat, int C, double count, float eps, const float* gamma,
+                      const float* beta, float* run_mean, float* run_var, long long* nbt, float momentum, int reps,
+                      int training, float* scale, float* shift, float* mean, float* invstd);
+int mmvqa_bn_coef_bwd(mmvqa_stream_t s, const double* stat, int C, double count, const float* gamma,
+                      const float* mean, const float* invstd, int training, float* P, float* Q, float* R,
+                      float* dgamma, float* dbeta);
+int mmvqa_bn_add_relu(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, const float* idn,
+                      const float* id_sc, const float* id_sh, float* out, long rows, int C);
+int mmvqa_maxpool_fwd(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, float* out,
+                      unsigned char* idx, int N, int H, int W, int C, int OH, int OW);
+int mmvqa_maxpool_bwd(mmvqa_stream_t s, const float* gp, const unsigned char* idx, const float* extra,
+                      const float* z, const float* sc, const float* sh, const float* mean, const float* invstd,
+                      float* g0, double* stat, int N, int H, int W, int C, int OH, int OW);
+/* LayerNorm over the last axis, optional residual input (y = LN(x + res)) */
+int mmvqa_layernorm_fwd(mmvqa_stream_t s, const float* x, const float* res, const float* gamma, const float* beta,
+                        float* y, float* sum_out, float* mean, float* rstd, int rows, int H, float eps);
+int mmvqa_layernorm_bwd(mmvqa_stream_t s, const float* dy, const float* x, const float* gamma, const float* mean,
+                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta, int rows,
+                        int H);
+/* HF BertEmbeddings + visual-token overwrite (models/mmbert.py:60-67); vis is [num_vis][B][H] */
+int mmvqa_embed_fwd(mmvqa_stream_t s, const long long* ids, const long long* seg, const float* word,
+                    const float* pos, const float* type, const float* gamma, const float* beta, const float* vis,
+                    float* out, float* xhat, float* rstd, int B, int T, int H, int num_vis, float eps,
+                    float drop_p, uint32_t seed);
+int mmvqa_embed_bwd(mmvqa_stream_t s, const float* dout, const long long* ids, const long long* seg,
+                    const float* xhat, const float* rstd, const float* gamma, float* dword, float* dpos,
+                    float* dtype, float* dgamma, float* dbeta, float* dvis, int B, int T, int H, int num_vis,
+                    float drop_p, uint32_t seed, int pad_idx);
+int mmvqa_meanpool_fwd(mmvqa_stream_t s, const float* h, const long long* mask, float* out, int B, int T, int H);
+int mmvqa_meanpool_bwd(mmvqa_stream_t s, const float* dout, const long long* mask, float* dh, int B, int T, int H,
+                       int accumulate);
+/* log_softmax + NLLLoss() + masked argmax accuracy (pretrain/roco_utils.py:235-236,257-265).
+ * out3 = {mean loss, #target>0, #correct}.  dlogits (nullable) = (softmax - onehot) * (*gscale_ptr) * gscale_mul */
+int mmvqa_mlm_loss(mmvqa_stream_t s, const float* logits, int ld, const long long* target, float* row_loss,
+                   long long* pred, float* dlogits, int dld, const float* gscale_ptr, float gscale_mul, int rows,
+                   int V, float* out3);
+/* ASLSingleLabel (models/asl_singlelabel.py:23-53): per-sample losses + dlogits*gscale */
+int mmvqa_asl_loss(mmvqa_stream_t s, const float* logits, int ld, const long long* target, float* row_loss,
+                   float* dlogits, int dld, int rows, int C, float gamma_pos, float gamma_neg, float eps,
+                   float gscale);
+int mmvqa_l2norm_fwd(mmvqa_stream_t s, const float* x, float* y, float* nrm, int rows, int D);
+int mmvqa_l2norm_bwd(mmvqa_stream_t s, const float* dy, const float* y, const float* nrm, float* dx, int rows,
+                     int D);
+/* SupConLoss.forward(features) without labels/mask = SimCLR (models/SupConLoss/loss.py:21-98);
+ * f is [2N][D] view-major */
+int mmvqa_supcon_loss(mmvqa_stream_t s, const float* f, float* loss, float* df, int N, int D, float temp,
+                      float base_temp, float gscale);
+/* torch.optim.Adam defaults over a flat buffer; g is scaled by gscale first and zeroed when zero_grad != 0 */
+int mmvqa_adam(mmvqa_stream_t s, float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2,
+               float eps, int step, float gscale, int zero_grad);
+int mmvqa_axpy(mmvqa_stream_t s, float* y, const float* x, float a, long n);
+int mmvqa_colsum(mmvqa_stream_t s, const float* x, int ld, int rows, int cols, float* out);
+int mmvqa_dropout(mmvqa_stream_t s, float* x, long n, float p, uint32_t seed);
+
+/* ---- engine level: the whole Model.forward / backward (models/mmbert.py:150-167) ------------ */
+int mmvqa_engine_create(const mmvqa_model_desc* desc, mmvqa_engine** out);
+void mmvqa_engine_destroy(mmvqa_engine* e);
+/* parameter / buffer table: names follow the reference state_dict.
+ * kind: 0 = trainable fp32 (offset into params/grads), 1 = fp32 buffer (offset into bufs),
+ *       2 = int64 buffer (offset into nbt).  shape is the LOGICAL torch shape; channels_last != 0
+ *       means the physical order is [d0][d2][d3][d1]. */
+int mmvqa_engine_num_tensors(const mmvqa_engine* e);
+int mmvqa_engine_tensor_info(const mmvqa_engine* e, int i, char* name, int name_cap, int* kind, int* ndim,
+                             long long shape[4], long long* offset, int* channels_last);
+long long mmvqa_engine_param_floats(const mmvqa_engine* e);
+long long mmvqa_engine_buf_floats(const mmvqa_engine* e);
+long long mmvqa_engine_nbt_count(const mmvqa_engine* e);
+/* plan for a batch geometry; returns workspace bytes needed (0 on error) */
+size_t mmvqa_engine_plan(mmvqa_engine* e, int B, int T, int img_h, int img_w);
+int mmvqa_engine_bind(mmvqa_engine* e, float* params, float* grads, float* bufs, long long* nbt, void* workspace,
+                      size_t workspace_bytes);
+/* img fp32 NCHW [B,3,h,w]; ids/seg/mask int64 [B,T]; logits [rows][ld] (rows = B*T or B);
+ * feat [B][feat_dim] or NULL.  training != 0: batch-stat BN + dropout with `seed`. */
+int mmvqa_engine_forward(mmvqa_engine* e, mmvqa_stream_t s, const float* img, const long long* ids,
+                         const long long* seg, const long long* mask, float* logits, int logits_ld, float* feat,
+                         int training, uint32_t seed);
+/* accumulates into grads; dlogits same layout as logits; dfeat nullable */
+int mmvqa_engine_backward(mmvqa_engine* e, mmvqa_stream_t s, const float* dlogits, int dlogits_ld,
+                          const float* dfeat);
+/* per-kernel-class timing (HIP events on the launch stream) of the NEXT forward+backward:
+ * enable, run, then read back {n_launches, total_ms, algorithmic_flops} per class */
+int mmvqa_engine_profile(mmvqa_engine* e, int enable);
+int mmvqa_engine_profile_read(mmvqa_engine* e, int cls, long long* launches, double* ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMVQA_H */

@@ -1,0 +1,159 @@
+"""ctypes binding of libmmvqa_hip.so (C ABI: include/mmvqa.h).
+
+The product path has NO fallback: if the shared library is missing or fails to
+load, every entry point raises.  Build it with ``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C mm-vqa_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmvqa_hip.so")
+
+c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+c_ptr = C.c_void_p
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SERF = 0, 1, 2, 3
+KIND_FWD, KIND_DGRAD, KIND_WGRAD = 0, 1, 2
+PRO_NONE, PRO_AFFINE_RELU, PRO_DZ, PRO_AFFINE = 0, 1, 2, 3
+EPI_PLAIN, EPI_TAP_FWD, EPI_TAP_BWD = 0, 1, 2
+STAT_SLOTS = 16
+
+
+class GemmDesc(C.Structure):
+    """mirror of mmvqa_gemm_desc"""
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("splitk", C.c_int), ("ktiles_per_split", C.c_int),
+        ("A", c_ptr), ("A2", c_ptr), ("a_c0", c_ptr), ("a_c1", c_ptr), ("a_c2", c_ptr),
+        ("a_pro", C.c_int), ("a_ld", C.c_int),
+        ("B", c_ptr), ("b_c0", c_ptr), ("b_c1", c_ptr), ("b_pro", C.c_int), ("b_ld", C.c_int),
+        ("b_tapstride", C.c_int),
+        ("g_SH", C.c_int), ("g_SW", C.c_int), ("g_Cs", C.c_int), ("g_OH", C.c_int), ("g_OW", C.c_int),
+        ("g_KH", C.c_int), ("g_KW", C.c_int), ("g_stride", C.c_int), ("g_pad", C.c_int), ("g_nchw", C.c_int),
+        ("C", c_ptr), ("c_ld", C.c_int), ("c_atomic", C.c_int), ("Cpre", c_ptr), ("bias", c_ptr),
+        ("act", C.c_int), ("dact", C.c_int), ("Pre", c_ptr), ("pre_ld", C.c_int),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("R", c_ptr), ("r_ld", C.c_int),
+        ("epi_mode", C.c_int), ("tap_HW", C.c_int), ("tap_out", c_ptr), ("tap_dv", c_ptr),
+        ("Mk", c_ptr), ("mk_ld", C.c_int), ("mk_s", c_ptr), ("mk_b", c_ptr),
+        ("stat1", c_ptr), ("stat_bwd", C.c_int), ("Z1", c_ptr), ("z1_ld", C.c_int), ("mean1", c_ptr),
+        ("invstd1", c_ptr),
+        ("stat2", c_ptr), ("Z2", c_ptr), ("z2_ld", C.c_int), ("mean2", c_ptr), ("invstd2", c_ptr),
+        ("colsum", c_ptr),
+    ]
+
+
+class AttnDesc(C.Structure):
+    """mirror of mmvqa_attn_desc"""
+    _fields_ = [
+        ("q", c_ptr), ("k", c_ptr), ("v", c_ptr), ("row_stride", C.c_int), ("head_stride", C.c_int),
+        ("out", c_ptr), ("out_row_stride", C.c_int), ("out_head_stride", C.c_int),
+        ("mask", c_ptr), ("mask_on_query", C.c_int), ("prev_in", c_ptr), ("prev_out", c_ptr), ("probs", c_ptr),
+        ("B", C.c_int), ("T", C.c_int), ("heads", C.c_int), ("sqrt_d", C.c_float), ("drop_p", C.c_float),
+        ("seed", C.c_uint32),
+        ("dout", c_ptr), ("dq", c_ptr), ("dk", c_ptr), ("dv", c_ptr), ("dprev_in", c_ptr), ("dprev_out", c_ptr),
+    ]
+
+
+class ModelDesc(C.Structure):
+    """mirror of mmvqa_model_desc"""
+    _fields_ = [
+        ("cnn", C.c_int), ("resnet_layers", C.c_int * 4), ("resnet_width", C.c_int), ("effnet_depth_div", C.c_int),
+        ("encoder", C.c_int), ("hidden", C.c_int), ("heads", C.c_int), ("n_layers", C.c_int),
+        ("emb_vocab", C.c_int), ("max_pos", C.c_int), ("type_vocab", C.c_int), ("num_vis", C.c_int),
+        ("head_kind", C.c_int), ("n_classes", C.c_int), ("supcon", C.c_int), ("feat_dim", C.c_int),
+        ("use_relu", C.c_int), ("p_drop", C.c_float), ("p_emb_drop", C.c_float), ("p_rf_drop", C.c_float),
+    ]
+
+
+# every symbol include/mmvqa.h declares, with (restype, argtypes); checked by tests/test_abi.py
+_i, _f, _d, _l, _ll, _u32, _sz = C.c_int, C.c_float, C.c_double, C.c_long, C.c_longlong, C.c_uint32, C.c_size_t
+_P = c_ptr
+SIGNATURES = {
+    "mmvqa_version": (_i, []),
+    "mmvqa_last_error": (C.c_char_p, []),
+    "mmvqa_sizeof_gemm_desc": (_sz, []),
+    "mmvqa_sizeof_attn_desc": (_sz, []),
+    "mmvqa_sizeof_model_desc": (_sz, []),
+    "mmvqa_igemm": (_i, [C.POINTER(GemmDesc), _i, _i, _i, _P]),
+    "mmvqa_attention": (_i, [C.POINTER(AttnDesc), _i, _i, _P]),
+    "mmvqa_bn_coef_fwd": (_i, [_P, _P, _i, _d, _f, _P, _P, _P, _P, _P, _f, _i, _i, _P, _P, _P, _P]),
+    "mmvqa_bn_coef_bwd": (_i, [_P, _P, _i, _d, _P, _P, _P, _i, _P, _P, _P, _P, _P]),
+    "mmvqa_bn_add_relu": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _l, _i]),
+    "mmvqa_maxpool_fwd": (_i, [_P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i]),
+    "mmvqa_maxpool_bwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i]),
+    "mmvqa_layernorm_fwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _f]),
+    "mmvqa_layernorm_bwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i]),
+    "mmvqa_embed_fwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _f, _f, _u32]),
+    "mmvqa_embed_bwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _f, _u32, _i]),
+    "mmvqa_meanpool_fwd": (_i, [_P, _P, _P, _P, _i, _i, _i]),
+    "mmvqa_meanpool_bwd": (_i, [_P, _P, _P, _P, _i, _i, _i, _i]),
+    "mmvqa_mlm_loss": (_i, [_P, _P, _i, _P, _P, _P, _P, _i, _P, _f, _i, _i, _P]),
+    "mmvqa_asl_loss": (_i, [_P, _P, _i, _P, _P, _P, _i, _i, _i, _f, _f, _f, _f]),
+    "mmvqa_l2norm_fwd": (_i, [_P, _P, _P, _P, _i, _i]),
+    "mmvqa_l2norm_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i]),
+    "mmvqa_supcon_loss": (_i, [_P, _P, _P, _P, _i, _i, _f, _f, _f]),
+    "mmvqa_adam": (_i, [_P, _P, _P, _P, _P, _l, _f, _f, _f, _f, _i, _f, _i]),
+    "mmvqa_axpy": (_i, [_P, _P, _P, _f, _l]),
+    "mmvqa_colsum": (_i, [_P, _P, _i, _i, _i, _P]),
+    "mmvqa_dropout": (_i, [_P, _P, _l, _f, _u32]),
+    "mmvqa_engine_create": (_i, [C.POINTER(ModelDesc), C.POINTER(_P)]),
+    "mmvqa_engine_destroy": (None, [_P]),
+    "mmvqa_engine_num_tensors": (_i, [_P]),
+    "mmvqa_engine_tensor_info": (_i, [_P, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll * 4),
+                                      C.POINTER(_ll), C.POINTER(_i)]),
+    "mmvqa_engine_param_floats": (_ll, [_P]),
+    "mmvqa_engine_buf_floats": (_ll, [_P]),
+    "mmvqa_engine_nbt_count": (_ll, [_P]),
+    "mmvqa_engine_plan": (_sz, [_P, _i, _i, _i, _i]),
+    "mmvqa_engine_bind": (_i, [_P, _P, _P, _P, _P, _P, _sz]),
+    "mmvqa_engine_forward": (_i, [_P, _P, _P, _P, _P, _P, _P, _i, _P, _i, _u32]),
+    "mmvqa_engine_backward": (_i, [_P, _P, _P, _i, _P]),
+    "mmvqa_engine_profile": (_i, [_P, _i]),
+    "mmvqa_engine_profile_read": (_i, [_P, _i, C.POINTER(_ll), C.POINTER(_d), C.POINTER(_d)]),
+}
+
+_lib = None
+
+
+class MMVQAError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MMVQAError(
+            f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback -- run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, no GPU required).")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    for nm, st in (("gemm", GemmDesc), ("attn", AttnDesc), ("model", ModelDesc)):
+        got = getattr(L, f"mmvqa_sizeof_{nm}_desc")()
+        if got != C.sizeof(st):
+            raise MMVQAError(f"ABI mismatch: sizeof(mmvqa_{nm}_desc) = {got} in the library, {C.sizeof(st)} in Python")
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = lib().mmvqa_last_error()
+        raise MMVQAError(f"mmvqa error {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """device/host pointer of a tensor (None -> NULL)"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,111 @@
+// Shared declarations for the gfx950 kernels of the MMBERT hot path.
+// Everything here is CDNA4-only: 64-wide wavefronts, fp32-input MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mmvqa.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SERF = 3 };
+// A/B operand prologues (applied when a tile is written to LDS)
+enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_DZ = 2, PRO_AFFINE = 3 };
+// epilogue special modes
+enum { EPI_PLAIN = 0, EPI_TAP_FWD = 1, EPI_TAP_BWD = 2 };
+// contraction kinds of the implicit-GEMM family (MMVQA_KIND_* in the ABI)
+enum { KIND_FWD = 0, KIND_DGRAD = 1, KIND_WGRAD = 2 };
+
+
+// One descriptor drives the three implicit-GEMM kernels (forward / dgrad / wgrad); it is part of
+// the C ABI (include/mmvqa.h).  Geometry ("g_") describes the gathered operand: rows of the row
+// space are pixels (n, oy, ox) over [g_OH, g_OW]; the source tensor is NHWC over [g_SH, g_SW] with
+// g_Cs channels per tap and ld floats per pixel.
+//   a_pro/b_pro : PRO_* prologue applied when a tile is written to LDS (coefficients per channel)
+//   A2          : second tensor of PRO_DZ (BatchNorm backward: dz = A*c0 + A2*c1 + c2)
+//   b_tapstride : dgrad: floats between taps inside one output-channel row of W
+//   g_nchw      : stem: source is NCHW [n][g_Cs][g_SH][g_SW], K index = (kh*KW+kw)*g_Cs + c
+//   epilogue order: +bias -> Cpre store -> *act'(Pre) -> act -> dropout -> +R -> ReLU mask (Mk)
+//                   -> store/atomicAdd -> column statistics (double, MMVQA_STAT_SLOTS replicas)
+typedef mmvqa_gemm_desc GemmParams;
+typedef mmvqa_attn_desc AttnParams;
+
+// --------------------------------------------------------------------------- device math
+__device__ __forceinline__ float act_fwd(int act, float x) {
+  switch (act) {
+    case ACT_RELU: return x > 0.f ? x : 0.f;
+    case ACT_GELU: return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    case ACT_SERF: {
+      float xc = x < 50.f ? x : 50.f;
+      return x * erff(log1pf(expf(xc)));
+    }
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ float act_bwd(int act, float x) {
+  switch (act) {
+    case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case ACT_GELU: {
+      float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+      float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case ACT_SERF: {
+      // d/dx [x erf(sp(min(x,50)))]; the clamp kills the inner derivative above 50
+      float xc = x < 50.f ? x : 50.f;
+      float e = expf(xc);
+      float sp = log1pf(e);
+      float er = erff(sp);
+      if (x > 50.f) return er;
+      float sig = e / (1.0f + e);
+      return er + x * 1.12837916709551257390f * expf(-sp * sp) * sig;
+    }
+    default: return 1.f;
+  }
+}
+
+// counter-based uniform in [0,1): (seed, index) -> float; identical in forward and backward
+__device__ __forceinline__ float rng_uniform(uint32_t seed, uint32_t idx) {
+  uint32_t x = idx * 0x9E3779B1u + seed;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  x += seed * 0x85ebca6bu;
+  x ^= x >> 13; x *= 0xc2b2ae35u;
+  x ^= x >> 16;
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// --------------------------------------------------------------------------- host side
+int mmvqa_set_error(int code, const char* fmt, ...);
+#define MMVQA_OK 0
+#define MMVQA_ERR_ARG -1
+#define MMVQA_ERR_HIP -2
+#define MMVQA_ERR_STATE -3
+
+#define HIP_CHECK_RET(expr)                                                               \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return mmvqa_set_error(MMVQA_ERR_HIP, "%s failed: %s (%s:%d)", #expr,               \
+                             hipGetErrorString(_e), __FILE__, __LINE__);                  \
+  } while (0)
+
+#define KERNEL_CHECK_RET() HIP_CHECK_RET(hipGetLastError())

@@ -1,0 +1,944 @@
+// HBM-bound primitives of the MMBERT path (gfx950): BatchNorm coefficient kernels, block-end
+// add+ReLU, max-pool, LayerNorm, embedding gather, mean-pool, vocab log-softmax/NLL, ASL,
+// SupCon, L2-normalise, Adam.  All use 16-byte accesses along the contiguous axis and
+// 64-lane wave reductions; per-channel sums are kept in double and spread over
+// MMVQA_STAT_SLOTS replicas to avoid same-address atomic serialisation.
+#include "common.h"
+
+static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
+
+// =========================================================================== BatchNorm coefficients
+// torchvision BatchNorm2d as the reference drives it (models/image_encoding.py:72-86):
+// train mode -> batch statistics (biased var) + running-stat update repeated `reps` times
+// with the same statistics; eval mode -> running statistics.
+__global__ void bn_coef_fwd_kernel(const double* __restrict__ stat, int C, double count, float eps,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ run_mean, float* __restrict__ run_var,
+                                   long long* __restrict__ nbt, float momentum, int reps, int training,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && nbt) *nbt += reps;
+  if (c >= C) return;
+  float mean, invstd;
+  if (training) {
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < MMVQA_STAT_SLOTS; ++k) {
+      s += stat[((size_t)k * C + c) * 2];
+      ss += stat[((size_t)k * C + c) * 2 + 1];
+    }
+    double mu = s / count;
+    double var = ss / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean = (float)mu;
+    invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+      double keep = pow(1.0 - (double)momentum, (double)reps);
+      double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+      run_mean[c] = (float)(keep * (double)run_mean[c] + (1.0 - keep) * mu);
+      run_var[c] = (float)(keep * (double)run_var[c] + (1.0 - keep) * unb);
+    }
+  } else {
+    mean = run_mean[c];
+    invstd = 1.0f / sqrtf(run_var[c] + eps);
+  }
+  float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  mean_out[c] = mean;
+  invstd_out[c] = invstd;
+}
+
+// dz = P*g + Q*z + R  with g = dL/d(bn output); also dgamma += sum g*xhat, dbeta += sum g
+__global__ void bn_coef_bwd_kernel(const double* __restrict__ stat, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ mean,
+                                   const float* __restrict__ invstd, int training,
+                                   float* __restrict__ P, float* __restrict__ Q, float* __restrict__ R,
+                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0.0, sgx = 0.0;
+  for (int k = 0; k < MMVQA_STAT_SLOTS; ++k) {
+    sg += stat[((size_t)k * C + c) * 2];
+    sgx += stat[((size_t)k * C + c) * 2 + 1];
+  }
+  double p = (double)gamma[c] * (double)invstd[c];
+  if (training) {
+    double c1 = sg / count, c2 = sgx / count;
+    P[c] = (float)p;
+    Q[c] = (float)(-p * c2 * (double)invstd[c]);
+    R[c] = (float)(p * (c2 * (double)invstd[c] * (double)mean[c] - c1));
+  } else {  // eval-mode BN is a fixed affine map
+    P[c] = (float)p; Q[c] = 0.f; R[c] = 0.f;
+  }
+  dgamma[c] += (float)sgx;
+  dbeta[c] += (float)sg;
+}
+
+// =========================================================================== block end: relu(bn3(z3) + identity)
+__global__ void bn_add_relu_kernel(const float* __restrict__ z, const float* __restrict__ s,
+                                   const float* __restrict__ b, const float* __restrict__ idn,
+                                   const float* __restrict__ ids, const float* __restrict__ idb,
+                                   float* __restrict__ out, long n4, int C4) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    int c = (int)(i % C4) * 4;
+    f32x4 zv = reinterpret_cast<const f32x4*>(z)[i];
+    f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c);
+    f32x4 iv = reinterpret_cast<const f32x4*>(idn)[i];
+    if (ids) {
+      f32x4 s2 = *reinterpret_cast<const f32x4*>(ids + c), b2 = *reinterpret_cast<const f32x4*>(idb + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) iv[j] = iv[j] * s2[j] + b2[j];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { float t = zv[j] * sv[j] + bv[j] + iv[j]; o[j] = t > 0.f ? t : 0.f; }
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
+// =========================================================================== max-pool 3x3 s2 p1 on relu(bn(z))
+__global__ void maxpool_fwd_kernel(const float* __restrict__ z, const float* __restrict__ s,
+                                   const float* __restrict__ b, float* __restrict__ out,
+                                   unsigned char* __restrict__ idx, int N, int H, int W, int C, int OH, int OW) {
+  const int C4 = C / 4;
+  long total = (long)N * OH * OW * C4;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    int c = (int)(i % C4) * 4;
+    long pix = i / C4;
+    int ox = (int)(pix % OW); long t = pix / OW;
+    int oy = (int)(t % OH); int n = (int)(t / OH);
+    f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      int y = oy * 2 - 1 + kh;
+      if (y < 0 || y >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        int x = ox * 2 - 1 + kw;
+        if (x < 0 || x >= W) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(z + ((size_t)(n * H + y) * W + x) * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a = v[j] * sv[j] + bv[j];
+          a = a > 0.f ? a : 0.f;
+          if (a > best[j]) { best[j] = a; bi[j] = kh * 3 + kw; }
+        }
+      }
+    }
+    reinterpret_cast<f32x4*>(out)[i] = best;
+    uchar4 u; u.x = bi[0]; u.y = bi[1]; u.z = bi[2]; u.w = bi[3];
+    reinterpret_cast<uchar4*>(idx)[i] = u;
+  }
+}
+
+// g0 = (maxpool_bwd(gp) + extra) * [relu(bn(z)) > 0]; accumulates BN-backward sums of bn(z).
+// blockDim = 256, C4 must divide 256 so that a thread keeps its channel quad across the grid-stride loop.
+__global__ void maxpool_bwd_kernel(const float* __restrict__ gp, const unsigned char* __restrict__ idx,
+                                   const float* __restrict__ extra, const float* __restrict__ z,
+                                   const float* __restrict__ s, const float* __restrict__ b,
+                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                   float* __restrict__ g0, double* __restrict__ stat,
+                                   int N, int H, int W, int C, int OH, int OW) {
+  const int C4 = C / 4;
+  long total = (long)N * H * W * C4;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  const int c = (int)(i % C4) * 4;
+  f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c);
+  f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+  double sg[4] = {0, 0, 0, 0}, sgx[4] = {0, 0, 0, 0};
+  for (; i < total; i += stride) {
+    long pix = i / C4;
+    int x = (int)(pix % W); long t = pix / W;
+    int y = (int)(t % H); int n = (int)(t / H);
+    f32x4 g = extra ? reinterpret_cast<const f32x4*>(extra)[i] : f32x4{0, 0, 0, 0};
+    int oy0 = y >> 1, ox0 = x >> 1;  // windows oy with oy*2-1 <= y <= oy*2+1
+    for (int oy = oy0; oy <= oy0 + 1; ++oy) {
+      int kh = y - (oy * 2 - 1);
+      if (kh < 0 || kh > 2 || oy >= OH) continue;
+      for (int ox = ox0; ox <= ox0 + 1; ++ox) {
+        int kw = x - (ox * 2 - 1);
+        if (kw < 0 || kw > 2 || ox >= OW) continue;
+        size_t o = ((size_t)(n * OH + oy) * OW + ox) * C + c;
+        uchar4 u = *reinterpret_cast<const uchar4*>(idx + o);
+        f32x4 gv = *reinterpret_cast<const f32x4*>(gp + o);
+        int code = kh * 3 + kw;
+        if (u.x == code) g[0] += gv[0];
+        if (u.y == code) g[1] += gv[1];
+        if (u.z == code) g[2] += gv[2];
+        if (u.w == code) g[3] += gv[3];
+      }
+    }
+    f32x4 zv = reinterpret_cast<const f32x4*>(z)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = zv[j] * sv[j] + bv[j];
+      if (!(a > 0.f)) g[j] = 0.f;
+      sg[j] += (double)g[j];
+      sgx[j] += (double)(g[j] * ((zv[j] - mu[j]) * is[j]));
+    }
+    reinterpret_cast<f32x4*>(g0)[i] = g;
+  }
+  // block reduction over the threads that share a channel quad (tid % C4)
+  __shared__ double red[256 * 8];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = sg[j]; red[tid * 8 + 4 + j] = sgx[j]; }
+  __syncthreads();
+  if (tid < C4) {
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = tid; t < 256; t += C4)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += red[t * 8 + j];
+    int slot = blockIdx.x & (MMVQA_STAT_SLOTS - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double* d = stat + ((size_t)slot * C + tid * 4 + j) * 2;
+      atomicAdd(d, a[j]);
+      atomicAdd(d + 1, a[4 + j]);
+    }
+  }
+}
+
+// =========================================================================== LayerNorm (one wave per row)
+#define LN_MAXV 4  // H <= 1024
+__global__ void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float* __restrict__ y, float* __restrict__ sum_out,
+                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                     int rows, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int H4 = H / 4;
+  f32x4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int q = lane + 64 * j;
+    v[j] = f32x4{0, 0, 0, 0};
+    if (q < H4) {
+      v[j] = reinterpret_cast<const f32x4*>(x + (size_t)row * H)[q];
+      if (res) {
+        f32x4 r = reinterpret_cast<const f32x4*>(res + (size_t)row * H)[q];
+        v[j] += r;
+        if (sum_out) reinterpret_cast<f32x4*>(sum_out + (size_t)row * H)[q] = v[j];
+      }
+      s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    }
+  }
+  float mean = wave_sum(s) / (float)H;
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int q = lane + 64 * j;
+    if (q < H4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float d = v[j][e] - mean; ss += d * d; }
+    }
+  }
+  float var = wave_sum(ss) / (float)H;
+  float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int q = lane + 64 * j;
+    if (q < H4) {
+      f32x4 g = reinterpret_cast<const f32x4*>(gamma)[q], b = reinterpret_cast<const f32x4*>(beta)[q], o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * g[e] + b[e];
+      reinterpret_cast<f32x4*>(y + (size_t)row * H)[q] = o;
+    }
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// dx = rstd*(dy*g - mean(dy*g) - xhat*mean(dy*g*xhat)) (+ dres); dgamma/dbeta accumulated with
+// float atomics after a per-workgroup reduction through LDS.
+__global__ void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                     float* __restrict__ dx, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int rows, int H, int rows_per_wave) {
+  extern __shared__ float lds[];  // [2][H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int H4 = H / 4;
+  for (int i = threadIdx.x; i < 2 * H; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  f32x4 ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) { ag[j] = f32x4{0, 0, 0, 0}; ab[j] = f32x4{0, 0, 0, 0}; }
+  const int row0 = (blockIdx.x * nw + wave) * rows_per_wave;
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
+    const int row = row0 + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[LN_MAXV], dg[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      int q = lane + 64 * j;
+      xh[j] = f32x4{0, 0, 0, 0}; dg[j] = f32x4{0, 0, 0, 0};
+      if (q < H4) {
+        f32x4 xv = reinterpret_cast<const f32x4*>(x + (size_t)row * H)[q];
+        f32x4 d = reinterpret_cast<const f32x4*>(dy + (size_t)row * H)[q];
+        f32x4 g = reinterpret_cast<const f32x4*>(gamma)[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[j][e] = (xv[e] - mu) * rs;
+          dg[j][e] = d[e] * g[e];
+          s1 += dg[j][e];
+          s2 += dg[j][e] * xh[j][e];
+          ag[j][e] += d[e] * xh[j][e];
+          ab[j][e] += d[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      int q = lane + 64 * j;
+      if (q < H4) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (dg[j][e] - s1 - xh[j][e] * s2);
+        if (dres) o += reinterpret_cast<const f32x4*>(dres + (size_t)row * H)[q];
+        reinterpret_cast<f32x4*>(dx + (size_t)row * H)[q] = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int q = lane + 64 * j;
+    if (q < H4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(&lds[q * 4 + e], ag[j][e]);
+        atomicAdd(&lds[H + q * 4 + e], ab[j][e]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    atomicAdd(&dgamma[i], lds[i]);
+    atomicAdd(&dbeta[i], lds[H + i]);
+  }
+}
+
+// =========================================================================== embeddings + visual-token overwrite
+// HF BertEmbeddings (call site models/mmbert.py:63) + prepare_input overwrite (mmbert.py:64-66):
+// row (b,t): t < num_vis -> vis[t][b][:]; else dropout(LN(word[id]+type[seg]+pos[t])).
+__global__ void embed_fwd_kernel(const long long* __restrict__ ids, const long long* __restrict__ seg,
+                                 const float* __restrict__ word, const float* __restrict__ pos,
+                                 const float* __restrict__ type, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ vis,
+                                 float* __restrict__ out, float* __restrict__ xhat_out,
+                                 float* __restrict__ rstd_out, int B, int T, int H, int num_vis,
+                                 float eps, float drop_p, uint32_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= B * T) return;
+  const int b = row / T, t = row - b * T;
+  const int H4 = H / 4;
+  if (t < num_vis) {
+    for (int q = lane; q < H4; q += 64)
+      reinterpret_cast<f32x4*>(out + (size_t)row * H)[q] =
+          reinterpret_cast<const f32x4*>(vis + ((size_t)t * B + b) * H)[q];
+    return;
+  }
+  const long long id = ids[row], sg = seg[row];
+  f32x4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int q = lane + 64 * j;
+    v[j] = f32x4{0, 0, 0, 0};
+    if (q < H4) {
+      f32x4 w = reinterpret_cast<const f32x4*>(word + (size_t)id * H)[q];
+      f32x4 ty = reinterpret_cast<const f32x4*>(type + (size_t)sg * H)[q];
+      f32x4 p = reinterpret_cast<const f32x4*>(pos + (size_t)t * H)[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[j][e] = (w[e] + ty[e]) + p[e];
+      s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    }
+  }
+  float mean = wave_sum(s) / (float)H;
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int q = lane + 64 * j;
+    if (q < H4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float d = v[j][e] - mean; ss += d * d; }
+    }
+  }
+  float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)H + eps);
+  const float ks = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int q = lane + 64 * j;
+    if (q < H4) {
+      f32x4 g = reinterpret_cast<const f32x4*>(gamma)[q], be = reinterpret_cast<const f32x4*>(beta)[q], o, xh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[e] = (v[j][e] - mean) * rstd;
+        o[e] = xh[e] * g[e] + be[e];
+        if (drop_p > 0.f) {
+          float u = rng_uniform(seed, (uint32_t)row * (uint32_t)H + q * 4 + e);
+          o[e] = (u >= drop_p) ? o[e] * ks : 0.f;
+        }
+      }
+      reinterpret_cast<f32x4*>(out + (size_t)row * H)[q] = o;
+      if (xhat_out) reinterpret_cast<f32x4*>(xhat_out + (size_t)row * H)[q] = xh;
+    }
+  }
+  if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+}
+
+// word_embeddings has padding_idx = 0 (HF BertConfig.pad_token_id): row 0 never receives gradient.
+__global__ void embed_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ ids,
+                                 const long long* __restrict__ seg, const float* __restrict__ xhat,
+                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                 float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype,
+                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dvis,
+                                 int B, int T, int H, int num_vis, float drop_p, uint32_t seed, int pad_idx) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= B * T) return;
+  const int b = row / T, t = row - b * T;
+  const int H4 = H / 4;
+  if (t < num_vis) {
+    for (int q = lane; q < H4; q += 64)
+      reinterpret_cast<f32x4*>(dvis + ((size_t)t * B + b) * H)[q] =
+          reinterpret_cast<const f32x4*>(dout + (size_t)row * H)[q];
+    return;
+  }
+  const long long id = ids[row], sg = seg[row];
+  const float rs = rstd[row];
+  const float ks = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+  f32x4 xh[LN_MAXV], dg[LN_MAXV];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int q = lane + 64 * j;
+    xh[j] = f32x4{0, 0, 0, 0}; dg[j] = f32x4{0, 0, 0, 0};
+    if (q < H4) {
+      f32x4 d = reinterpret_cast<const f32x4*>(dout + (size_t)row * H)[q];
+      xh[j] = reinterpret_cast<const f32x4*>(xhat + (size_t)row * H)[q];
+      f32x4 g = reinterpret_cast<const f32x4*>(gamma)[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (drop_p > 0.f) {
+          float u = rng_uniform(seed, (uint32_t)row * (uint32_t)H + q * 4 + e);
+          d[e] = (u >= drop_p) ? d[e] * ks : 0.f;
+        }
+        atomicAdd(&dgamma[q * 4 + e], d[e] * xh[j][e]);
+        atomicAdd(&dbeta[q * 4 + e], d[e]);
+        dg[j][e] = d[e] * g[e];
+        s1 += dg[j][e];
+        s2 += dg[j][e] * xh[j][e];
+      }
+    }
+  }
+  s1 = wave_sum(s1) / (float)H;
+  s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    int q = lane + 64 * j;
+    if (q < H4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float de = rs * (dg[j][e] - s1 - xh[j][e] * s2);
+        if (id != pad_idx) atomicAdd(&dword[(size_t)id * H + q * 4 + e], de);
+        atomicAdd(&dtype[(size_t)sg * H + q * 4 + e], de);
+        atomicAdd(&dpos[(size_t)t * H + q * 4 + e], de);
+      }
+    }
+  }
+}
+
+// =========================================================================== mean pooling (models/mmbert.py:169-172)
+__global__ void meanpool_fwd_kernel(const float* __restrict__ h, const long long* __restrict__ mask,
+                                    float* __restrict__ out, int B, int T, int H) {
+  int b = blockIdx.x;
+  float cnt = 0.f;
+  for (int t = 0; t < T; ++t) cnt += (float)mask[b * T + t];
+  float denom = fmaxf(cnt, 1e-9f);
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += h[((size_t)b * T + t) * H + c] * (float)mask[b * T + t];
+    out[(size_t)b * H + c] = s / denom;
+  }
+}
+// dh (+)= dout * mask / denom
+__global__ void meanpool_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ mask,
+                                    float* __restrict__ dh, int B, int T, int H, int accumulate) {
+  int b = blockIdx.x;
+  float cnt = 0.f;
+  for (int t = 0; t < T; ++t) cnt += (float)mask[b * T + t];
+  float denom = fmaxf(cnt, 1e-9f);
+  for (int i = threadIdx.x; i < T * H; i += blockDim.x) {
+    int t = i / H, c = i - t * H;
+    float v = dout[(size_t)b * H + c] * (float)mask[b * T + t] / denom;
+    size_t o = ((size_t)b * T + t) * H + c;
+    dh[o] = accumulate ? dh[o] + v : v;
+  }
+}
+
+// =========================================================================== vocab log-softmax + NLL + argmax
+// pretrain/roco_utils.py:235-236,257-265.  One workgroup per row.  Writes row loss
+// (lse - logit[target]), first-index argmax, and (optionally) dlogits = (softmax - onehot) * gscale.
+__global__ void lsm_nll_kernel(const float* __restrict__ logits, int ld, const long long* __restrict__ target,
+                               float* __restrict__ row_loss, long long* __restrict__ pred,
+                               float* __restrict__ dlogits, int dld, const float* __restrict__ gscale_ptr,
+                               float gscale_mul, int V) {
+  __shared__ float red_m[4], red_s[4];
+  __shared__ int red_i[4];
+  const int row = blockIdx.x;
+  const float* x = logits + (size_t)row * ld;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float m = -INFINITY; int mi = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {
+    float v = x[i];
+    if (v > m) { m = v; mi = i; }
+  }
+  // wave argmax (first index on ties)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float om = __shfl_xor(m, o, 64); int oi = __shfl_xor(mi, o, 64);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  if (lane == 0) { red_m[wave] = m; red_i[wave] = mi; }
+  __syncthreads();
+  m = red_m[0]; mi = red_i[0];
+  for (int w = 1; w < 4; ++w) if (red_m[w] > m || (red_m[w] == m && red_i[w] < mi)) { m = red_m[w]; mi = red_i[w]; }
+  float s = 0.f;
+  for (int i = threadIdx.x; i < V; i += blockDim.x) s += expf(x[i] - m);
+  s = wave_sum(s);
+  if (lane == 0) red_s[wave] = s;
+  __syncthreads();
+  s = red_s[0] + red_s[1] + red_s[2] + red_s[3];
+  const float lse = m + logf(s);
+  const long long tg = target[row];
+  if (threadIdx.x == 0) {
+    row_loss[row] = lse - x[tg];
+    pred[row] = mi;
+  }
+  if (dlogits) {
+    const float gs = (gscale_ptr ? *gscale_ptr : 1.0f) * gscale_mul;
+    float* d = dlogits + (size_t)row * dld;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+      float pr = expf(x[i] - lse);
+      d[i] = (pr - (i == tg ? 1.f : 0.f)) * gs;
+    }
+  }
+}
+
+// loss = mean(row_loss); n_masked = #(target>0); n_correct = #(target>0 && pred==target)
+__global__ void mlm_reduce_kernel(const float* __restrict__ row_loss, const long long* __restrict__ pred,
+                                  const long long* __restrict__ target, int rows, float* __restrict__ out3) {
+  float s = 0.f, nm = 0.f, nc = 0.f;
+  for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+    s += row_loss[i];
+    if (target[i] > 0) { nm += 1.f; if (pred[i] == target[i]) nc += 1.f; }
+  }
+  __shared__ float red[3][4];
+  s = wave_sum(s); nm = wave_sum(nm); nc = wave_sum(nc);
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s; red[1][wave] = nm; red[2][wave] = nc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out3[0] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)rows;
+    out3[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    out3[2] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+  }
+}
+
+// =========================================================================== ASL single-label (models/asl_singlelabel.py:23-53)
+// One workgroup per sample; loss_b = -sum_j t~_j w_j lp_j with w_target = (1-p_t)^gp... (gamma_pos on the
+// target, gamma_neg elsewhere); writes per-sample loss and dlogits * gscale / B.
+__global__ void asl_kernel(const float* __restrict__ logits, int ld, const long long* __restrict__ target,
+                           float* __restrict__ row_loss, float* __restrict__ dlogits, int dld, int C,
+                           float gpos, float gneg, float eps, float gscale) {
+  __shared__ float red[4];
+  __shared__ float bc;
+  const int row = blockIdx.x;
+  const float* x = logits + (size_t)row * ld;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tg = (int)target[row];
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) m = fmaxf(m, x[i]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) s += expf(x[i] - m);
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float lse = m + logf(red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();
+  // loss and G_j = dL/d lp_j ; dlogit_k = G_k - p_k * sum_j G_j
+  float loss = 0.f, gsum = 0.f;
+  const float tsm_o = eps / (float)C;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    float lp = x[i] - lse, p = expf(lp);
+    bool is_t = (i == tg);
+    float ts = (is_t ? (1.f - eps) : 0.f) + tsm_o;
+    float base = is_t ? (1.f - p) : p;      // 1 - xs_pos*t - xs_neg*anti
+    float gam = is_t ? gpos : gneg;
+    float w = (gam == 0.f) ? 1.f : powf(base, gam);
+    loss += -ts * w * lp;
+    // dw/dlp = gam * base^(gam-1) * dbase/dlp ; dbase/dlp = (is_t ? -p : p)
+    float dw = (gam == 0.f) ? 0.f : gam * powf(base, gam - 1.f) * (is_t ? -p : p);
+    float G = -ts * (w + lp * dw);
+    gsum += G;
+    if (dlogits) dlogits[(size_t)row * dld + i] = G;  // finished below
+  }
+  loss = wave_sum(loss); gsum = wave_sum(gsum);
+  if (lane == 0) red[wave] = loss;
+  __syncthreads();
+  if (threadIdx.x == 0) row_loss[row] = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  if (lane == 0) red[wave] = gsum;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  if (dlogits) {
+    const float gs = bc;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+      float p = expf(x[i] - lse);
+      size_t o = (size_t)row * dld + i;
+      dlogits[o] = (dlogits[o] - p * gs) * gscale;
+    }
+  }
+}
+
+// =========================================================================== L2 normalise rows (F.normalize, eps 1e-12)
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ nrm,
+                                  int rows, int D) {
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) { float v = x[(size_t)row * D + i]; s += v * v; }
+  float n = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+  for (int i = lane; i < D; i += 64) y[(size_t)row * D + i] = x[(size_t)row * D + i] / n;
+  if (lane == 0) nrm[row] = n;
+}
+__global__ void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                  const float* __restrict__ nrm, float* __restrict__ dx, int rows, int D) {
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += dy[(size_t)row * D + i] * y[(size_t)row * D + i];
+  s = wave_sum(s);
+  float n = nrm[row];
+  for (int i = lane; i < D; i += 64)
+    dx[(size_t)row * D + i] = (dy[(size_t)row * D + i] - y[(size_t)row * D + i] * s) / n;
+}
+
+// =========================================================================== SupCon / SimCLR (models/SupConLoss/loss.py:21-98)
+// features f [R=2N, D] ordered view-major (cat(unbind(features,1))): positive of r is (r+N) mod 2N.
+// Single workgroup; writes loss and df (already scaled by gscale).
+__global__ void supcon_kernel(const float* __restrict__ f, float* __restrict__ loss_out, float* __restrict__ df,
+                              int N, int D, float temp, float base_temp, float gscale) {
+  extern __shared__ float sm[];  // z [R][R], then lse[R]
+  const int R = 2 * N;
+  float* z = sm;
+  float* lse = sm + R * R;
+  for (int i = threadIdx.x; i < R * R; i += blockDim.x) {
+    int a = i / R, b = i - a * R;
+    float s = 0.f;
+    for (int k = 0; k < D; ++k) s += f[(size_t)a * D + k] * f[(size_t)b * D + k];
+    z[i] = s / temp;
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < R; a += blockDim.x) {
+    float m = -INFINITY;
+    for (int b = 0; b < R; ++b) m = fmaxf(m, z[a * R + b]);
+    float s = 0.f;
+    for (int b = 0; b < R; ++b) if (b != a) s += expf(z[a * R + b] - m);
+    lse[a] = m + logf(s);
+  }
+  __syncthreads();
+  const float coef = temp / base_temp;
+  if (threadIdx.x == 0) {
+    float l = 0.f;
+    for (int a = 0; a < R; ++a) l += -(z[a * R + (a + N) % R] - lse[a]);
+    *loss_out = coef * l / (float)R;
+  }
+  if (df) {
+    // dL/dz[a][b] = coef/R * (softmax_{b!=a}(z[a])[b] - [b==pos(a)])
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * R; i += blockDim.x) {
+      int a = i / R, b = i - a * R;
+      float g = (b == a) ? 0.f : expf(z[i] - lse[a]);
+      if (b == (a + N) % R) g -= 1.f;
+      z[i] = g * coef / (float)R / temp * gscale;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * D; i += blockDim.x) {
+      int a = i / D, k = i - a * D;
+      float s = 0.f;
+      for (int b = 0; b < R; ++b) s += (z[a * R + b] + z[b * R + a]) * f[(size_t)b * D + k];
+      df[i] = s;
+    }
+  }
+}
+
+// =========================================================================== Adam (torch defaults; roco_train.py:90)
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n4, float lr, float b1, float b2, float eps,
+                            float bc1, float bc2_sqrt, float gscale, int zero_grad) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  const float step = lr / bc1;
+  for (; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gg = gv[e] * gscale;
+      mv[e] = mv[e] * b1 + gg * (1.f - b1);
+      vv[e] = vv[e] * b2 + gg * gg * (1.f - b2);
+      float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+      pv[e] = pv[e] - step * (mv[e] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (zero_grad) reinterpret_cast<f32x4*>(g)[i] = f32x4{0, 0, 0, 0};
+  }
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] += a * x[i];
+}
+
+// out[c] += sum_rows x[row][c]   (bias gradients of the outermost linears)
+__global__ void colsum_kernel(const float* __restrict__ x, int ld, int rows, int cols, float* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  int r0 = blockIdx.y * 64, r1 = min(rows, r0 + 64);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += x[(size_t)r * ld + c];
+  atomicAdd(&out[c], s);
+}
+
+// dropout applied in place on a dense tensor (used where no GEMM epilogue is available)
+__global__ void dropout_kernel(float* __restrict__ x, long n, float p, uint32_t seed) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  const float ks = 1.0f / (1.0f - p);
+  for (; i < n; i += stride) x[i] = (rng_uniform(seed, (uint32_t)i) >= p) ? x[i] * ks : 0.f;
+}
+
+// y = dropout(x) with the same (seed, linear index) stream as the GEMM epilogue; used on the
+// backward side of a residual branch: d(branch) = mask * dy / (1-p) while dy itself flows on.
+__global__ void dropout_copy_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
+                                    uint32_t seed) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  const float ks = 1.0f / (1.0f - p);
+  for (; i < n; i += stride) y[i] = (rng_uniform(seed, (uint32_t)i) >= p) ? x[i] * ks : 0.f;
+}
+
+// =========================================================================== host launchers
+static inline int grid_for(long n, int block = 256, int cap = 2048) {
+  long g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int k_bn_coef_fwd(hipStream_t st, const double* stat, int C, double count, float eps, const float* gamma,
+                  const float* beta, float* run_mean, float* run_var, long long* nbt, float momentum, int reps,
+                  int training, float* scale, float* shift, float* mean, float* invstd) {
+  hipLaunchKernelGGL(bn_coef_fwd_kernel, dim3(cdiv_i(C, 256)), dim3(256), 0, st, stat, C, count, eps, gamma, beta,
+                     run_mean, run_var, nbt, momentum, reps, training, scale, shift, mean, invstd);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_bn_coef_bwd(hipStream_t st, const double* stat, int C, double count, const float* gamma, const float* mean,
+                  const float* invstd, int training, float* P, float* Q, float* R, float* dgamma, float* dbeta) {
+  hipLaunchKernelGGL(bn_coef_bwd_kernel, dim3(cdiv_i(C, 256)), dim3(256), 0, st, stat, C, count, gamma, mean,
+                     invstd, training, P, Q, R, dgamma, dbeta);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_bn_add_relu(hipStream_t st, const float* z, const float* s, const float* b, const float* idn,
+                  const float* ids, const float* idb, float* out, long rows, int C) {
+  long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_add_relu_kernel, dim3(grid_for(n4)), dim3(256), 0, st, z, s, b, idn, ids, idb, out, n4,
+                     C / 4);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_maxpool_fwd(hipStream_t st, const float* z, const float* s, const float* b, float* out, unsigned char* idx,
+                  int N, int H, int W, int C, int OH, int OW) {
+  long total = (long)N * OH * OW * C / 4;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, z, s, b, out, idx, N, H, W, C,
+                     OH, OW);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_maxpool_bwd(hipStream_t st, const float* gp, const unsigned char* idx, const float* extra, const float* z,
+                  const float* s, const float* b, const float* mean, const float* invstd, float* g0, double* stat,
+                  int N, int H, int W, int C, int OH, int OW) {
+  if (C % 4 != 0 || 256 % (C / 4) != 0)
+    return mmvqa_set_error(MMVQA_ERR_ARG, "maxpool_bwd: C/4 must divide 256 (C=%d)", C);
+  long total = (long)N * H * W * C / 4;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), 0, st, gp, idx, extra, z, s,
+                     b, mean, invstd, g0, stat, N, H, W, C, OH, OW);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_layernorm_fwd(hipStream_t st, const float* x, const float* res, const float* gamma, const float* beta,
+                    float* y, float* sum_out, float* mean, float* rstd, int rows, int H, float eps) {
+  if (H % 4 != 0 || H > 256 * LN_MAXV) return mmvqa_set_error(MMVQA_ERR_ARG, "layernorm: H=%d unsupported", H);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv_i(rows, 4)), dim3(256), 0, st, x, res, gamma, beta, y,
+                     sum_out, mean, rstd, rows, H, eps);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_layernorm_bwd(hipStream_t st, const float* dy, const float* x, const float* gamma, const float* mean,
+                    const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int H) {
+  if (H % 4 != 0 || H > 256 * LN_MAXV) return mmvqa_set_error(MMVQA_ERR_ARG, "layernorm: H=%d unsupported", H);
+  int rpw = rows >= 2048 ? 4 : (rows >= 512 ? 2 : 1);
+  int grid = cdiv_i(rows, 4 * rpw);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), 2 * H * sizeof(float), st, dy, x, gamma, mean,
+                     rstd, dres, dx, dgamma, dbeta, rows, H, rpw);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_embed_fwd(hipStream_t st, const long long* ids, const long long* seg, const float* word, const float* pos,
+                const float* type, const float* gamma, const float* beta, const float* vis, float* out,
+                float* xhat, float* rstd, int B, int T, int H, int num_vis, float eps, float drop_p,
+                uint32_t seed) {
+  if (H % 4 != 0 || H > 256 * LN_MAXV) return mmvqa_set_error(MMVQA_ERR_ARG, "embed: H=%d unsupported", H);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(cdiv_i((long)B * T, 4)), dim3(256), 0, st, ids, seg, word, pos, type,
+                     gamma, beta, vis, out, xhat, rstd, B, T, H, num_vis, eps, drop_p, seed);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_embed_bwd(hipStream_t st, const float* dout, const long long* ids, const long long* seg, const float* xhat,
+                const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype, float* dgamma,
+                float* dbeta, float* dvis, int B, int T, int H, int num_vis, float drop_p, uint32_t seed,
+                int pad_idx) {
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(cdiv_i((long)B * T, 4)), dim3(256), 0, st, dout, ids, seg, xhat, rstd,
+                     gamma, dword, dpos, dtype, dgamma, dbeta, dvis, B, T, H, num_vis, drop_p, seed, pad_idx);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_meanpool_fwd(hipStream_t st, const float* h, const long long* mask, float* out, int B, int T, int H) {
+  hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B), dim3(256), 0, st, h, mask, out, B, T, H);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+int k_meanpool_bwd(hipStream_t st, const float* dout, const long long* mask, float* dh, int B, int T, int H,
+                   int accumulate) {
+  hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(B), dim3(256), 0, st, dout, mask, dh, B, T, H, accumulate);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_lsm_nll(hipStream_t st, const float* logits, int ld, const long long* target, float* row_loss,
+              long long* pred, float* dlogits, int dld, const float* gscale_ptr, float gscale_mul, int rows, int V,
+              float* out3) {
+  hipLaunchKernelGGL(lsm_nll_kernel, dim3(rows), dim3(256), 0, st, logits, ld, target, row_loss, pred, dlogits,
+                     dld, gscale_ptr, gscale_mul, V);
+  KERNEL_CHECK_RET();
+  if (out3) {
+    hipLaunchKernelGGL(mlm_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, pred, target, rows, out3);
+    KERNEL_CHECK_RET();
+  }
+  return MMVQA_OK;
+}
+
+int k_asl(hipStream_t st, const float* logits, int ld, const long long* target, float* row_loss, float* dlogits,
+          int dld, int rows, int C, float gpos, float gneg, float eps, float gscale) {
+  hipLaunchKernelGGL(asl_kernel, dim3(rows), dim3(256), 0, st, logits, ld, target, row_loss, dlogits, dld, C, gpos,
+                     gneg, eps, gscale);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_l2norm_fwd(hipStream_t st, const float* x, float* y, float* nrm, int rows, int D) {
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv_i(rows, 4)), dim3(256), 0, st, x, y, nrm, rows, D);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+int k_l2norm_bwd(hipStream_t st, const float* dy, const float* y, const float* nrm, float* dx, int rows, int D) {
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv_i(rows, 4)), dim3(256), 0, st, dy, y, nrm, dx, rows, D);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_supcon(hipStream_t st, const float* f, float* loss, float* df, int N, int D, float temp, float base_temp,
+             float gscale) {
+  int R = 2 * N;
+  size_t sm = ((size_t)R * R + R) * sizeof(float);
+  if (sm > 160 * 1024) return mmvqa_set_error(MMVQA_ERR_ARG, "supcon: 2N=%d too large for one workgroup", R);
+  if (sm > 48 * 1024)
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)supcon_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)sm));
+  hipLaunchKernelGGL(supcon_kernel, dim3(1), dim3(256), sm, st, f, loss, df, N, D, temp, base_temp, gscale);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_adam(hipStream_t st, float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+           int step, float gscale, int zero_grad) {
+  if (n % 4 != 0) return mmvqa_set_error(MMVQA_ERR_ARG, "adam: n must be a multiple of 4");
+  float bc1 = 1.0f - powf(b1, (float)step);
+  float bc2s = sqrtf(1.0f - powf(b2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, st, p, g, m, v, n / 4, lr, b1, b2,
+                     eps, bc1, bc2s, gscale, zero_grad);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_axpy(hipStream_t st, float* y, const float* x, float a, long n) {
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, st, y, x, a, n);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_colsum(hipStream_t st, const float* x, int ld, int rows, int cols, float* out) {
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv_i(cols, 256), cdiv_i(rows, 64)), dim3(256), 0, st, x, ld, rows, cols,
+                     out);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_dropout(hipStream_t st, float* x, long n, float p, uint32_t seed) {
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, p, seed);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_dropout_copy(hipStream_t st, const float* x, float* y, long n, float p, uint32_t seed) {
+  hipLaunchKernelGGL(dropout_copy_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n, p, seed);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}

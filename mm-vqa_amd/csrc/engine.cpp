@@ -1,0 +1,996 @@
+// Launch sequences of the MMBERT hot path (see engine.h).  Reference call stack: SURVEY.md 3.1-3.4.
+//
+//   forward : ResNet stem -> [tap] -> maxpool -> bottlenecks (+tap at every layer end)
+//             -> BertEmbeddings + visual-token overwrite -> 4x BertLayer | 4x ResEncoderBlock
+//             -> fc1/SERF/classifier (per token or mean-pooled) [+ SupCon head]
+//   backward: the exact reverse, every BatchNorm/ReLU/residual backward folded into GEMM
+//             prologues/epilogues (igemm.hip), weight gradients accumulated into `grads`.
+#include "engine.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+// --------------------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+int mmvqa_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+const char* mmvqa_get_error() { return g_err; }
+
+#define TRY(x)                    \
+  do {                            \
+    int _r = (x);                 \
+    if (_r != MMVQA_OK) return _r; \
+  } while (0)
+
+// --------------------------------------------------------------------------- parameter table
+namespace {
+
+struct Builder {
+  mmvqa_engine* e;
+  long long align4(long long x) { return (x + 3) & ~3LL; }
+  long long add(const std::string& name, int kind, std::initializer_list<long long> shape, int cl = 0) {
+    TensorSpec s;
+    s.name = name; s.kind = kind; s.ndim = (int)shape.size(); s.channels_last = cl;
+    long long n = 1; int i = 0;
+    for (auto v : shape) { s.shape[i++] = v; n *= v; }
+    for (; i < 4; ++i) s.shape[i] = 1;
+    long long& cur = kind == 0 ? e->n_params : (kind == 1 ? e->n_bufs : e->n_nbt);
+    if (kind != 2) cur = align4(cur);
+    s.offset = cur;
+    cur += n;
+    e->specs.push_back(s);
+    return s.offset;
+  }
+  ConvRef conv(const std::string& name, int cin, int cout, int k, int stride, int pad) {
+    ConvRef c; c.Cin = cin; c.Cout = cout; c.KH = k; c.stride = stride; c.pad = pad;
+    c.w = add(name + ".weight", 0, {cout, cin, k, k}, 1);
+    return c;
+  }
+  BNRef bn(const std::string& name, int C, int reps) {
+    BNRef b; b.C = C; b.reps = reps;
+    b.gamma = add(name + ".weight", 0, {C});
+    b.beta = add(name + ".bias", 0, {C});
+    b.rmean = add(name + ".running_mean", 1, {C});
+    b.rvar = add(name + ".running_var", 1, {C});
+    b.nbt = add(name + ".num_batches_tracked", 2, {});
+    return b;
+  }
+  LinRef lin(const std::string& name, int in, int out, bool bias) {
+    LinRef l; l.in = in; l.out = out;
+    l.w = add(name + ".weight", 0, {out, in});
+    l.b = bias ? add(name + ".bias", 0, {out}) : -1;
+    return l;
+  }
+  LNRef ln(const std::string& name, int H) {
+    LNRef l;
+    l.g = add(name + ".weight", 0, {H});
+    l.b = add(name + ".bias", 0, {H});
+    return l;
+  }
+};
+
+int build_tables(mmvqa_engine* e) {
+  const mmvqa_model_desc& d = e->d;
+  Builder b{e};
+  const int H = d.hidden;
+  // models/mmbert.py:52-56 -- HF BertEmbeddings
+  const std::string be = "transformer.bert_embedding.";
+  e->emb_word = b.add(be + "word_embeddings.weight", 0, {d.emb_vocab, H});
+  e->emb_pos = b.add(be + "position_embeddings.weight", 0, {d.max_pos, H});
+  e->emb_type = b.add(be + "token_type_embeddings.weight", 0, {d.type_vocab, H});
+  e->emb_ln = b.ln(be + "LayerNorm", H);
+  // models/image_encoding.py:43-62 -- backbone + tap convs
+  if (d.cnn != 0) return mmvqa_set_error(MMVQA_ERR_ARG, "engine: cnn=%d not built yet (resnet only)", d.cnn);
+  const std::string rm = "transformer.trans.model.";
+  const int w = d.resnet_width;
+  e->stem_conv = b.conv(rm + "conv1", 3, w, 7, 2, 3);
+  e->stem_bn = b.bn(rm + "bn1", w, 5);
+  int inpl = w;
+  for (int l = 0; l < 4; ++l) {
+    const int planes = w << l, stride = l == 0 ? 1 : 2, reps = 4 - l;
+    for (int k = 0; k < d.resnet_layers[l]; ++k) {
+      BlockRef blk;
+      const std::string p = rm + "layer" + std::to_string(l + 1) + "." + std::to_string(k) + ".";
+      const int s = k == 0 ? stride : 1;
+      blk.c1 = b.conv(p + "conv1", inpl, planes, 1, 1, 0);
+      blk.b1 = b.bn(p + "bn1", planes, reps);
+      blk.c2 = b.conv(p + "conv2", planes, planes, 3, s, 1);
+      blk.b2 = b.bn(p + "bn2", planes, reps);
+      blk.c3 = b.conv(p + "conv3", planes, planes * 4, 1, 1, 0);
+      blk.b3 = b.bn(p + "bn3", planes * 4, reps);
+      blk.has_ds = (k == 0);
+      if (blk.has_ds) {
+        blk.cd = b.conv(p + "downsample.0", inpl, planes * 4, 1, s, 0);
+        blk.bd = b.bn(p + "downsample.1", planes * 4, reps);
+      }
+      inpl = planes * 4;
+      e->blocks.push_back(blk);
+    }
+    e->layer_end[l] = (int)e->blocks.size() - 1;
+  }
+  b.add(rm + "fc.weight", 0, {1000, (long long)w * 32});  // exists in the state_dict, never used (quirk 2)
+  b.add(rm + "fc.bias", 0, {1000});
+  const char* tapn[5] = {"conv2", "conv3", "conv4", "conv5", "conv7"};
+  const int tapc[5] = {w * 32, w * 16, w * 8, w * 4, w};
+  for (int k = 0; k < 5; ++k) {
+    e->taps[k].C = tapc[k];
+    e->taps[k].w = b.add(std::string("transformer.trans.") + tapn[k] + ".weight", 0, {H, tapc[k], 1, 1}, 1);
+  }
+  // encoder
+  if (d.encoder == 0) {
+    const std::string bl = "transformer.blocks.";
+    e->norm1 = b.ln(bl + "norm1", H);
+    e->norm2 = b.ln(bl + "norm2", H);
+    e->bert.resize(d.n_layers);
+    for (int i = 0; i < d.n_layers; ++i) {
+      BertLayerRef& L = e->bert[i];
+      const std::string a = bl + "attention." + std::to_string(i) + ".";
+      // q,k,v weights (and biases) are laid out back to back: one fused [3H,H] projection
+      L.qkv.in = H; L.qkv.out = 3 * H;
+      L.qkv.w = b.add(a + "proj_q.weight", 0, {H, H});
+      long long kw = b.add(a + "proj_k.weight", 0, {H, H});
+      long long vw = b.add(a + "proj_v.weight", 0, {H, H});
+      L.qkv.b = b.add(a + "proj_q.bias", 0, {H});
+      long long kb = b.add(a + "proj_k.bias", 0, {H});
+      long long vb = b.add(a + "proj_v.bias", 0, {H});
+      if (kw != L.qkv.w + (long long)H * H || vw != kw + (long long)H * H || kb != L.qkv.b + H || vb != kb + H)
+        return mmvqa_set_error(MMVQA_ERR_STATE, "engine: qkv parameters are not contiguous (H=%d)", H);
+    }
+    for (int i = 0; i < d.n_layers; ++i) e->bert[i].proj = b.lin(bl + "proj." + std::to_string(i), H, H, true);
+    for (int i = 0; i < d.n_layers; ++i) {
+      const std::string f = bl + "feedforward." + std::to_string(i) + ".";
+      e->bert[i].fc1 = b.lin(f + "fc1", H, 4 * H, true);
+      e->bert[i].fc2 = b.lin(f + "fc2", 4 * H, H, true);
+    }
+  } else {
+    e->rf.resize(d.n_layers);
+    const int es = H / 8;
+    for (int i = 0; i < d.n_layers; ++i) {
+      RFLayerRef& L = e->rf[i];
+      const std::string m = "transformer.mains." + std::to_string(i) + ".";
+      L.kqv = b.lin(m + "kqv", es, 3 * es, false);
+      L.proj = b.lin(m + "proj", H, H, false);
+      L.ln1 = b.ln(m + "ln1", H);
+      L.ln2 = b.ln(m + "ln2", H);
+      L.ff0 = b.lin(m + "ff.0", H, 4 * H, true);
+      L.ff2 = b.lin(m + "ff.2", 4 * H, H, true);
+    }
+  }
+  // heads (models/mmbert.py:133-148)
+  e->fc1 = b.lin("fc1", H, H, true);
+  e->cls0 = b.lin("classifier.0", H, H, true);
+  e->cls_ln = b.ln("classifier.1", H);
+  e->cls2 = b.lin("classifier.2", H, d.n_classes, true);
+  if (d.supcon) {
+    e->head0 = b.lin("head.0", H, H, true);
+    e->head2 = b.lin("head.2", H, d.feat_dim, true);
+  }
+  e->n_params = b.align4(e->n_params);
+  e->n_bufs = b.align4(e->n_bufs);
+  return MMVQA_OK;
+}
+
+// --------------------------------------------------------------------------- workspace plan
+struct Arena {
+  size_t cur = 0;
+  size_t f(size_t n) {  // floats, 64-float (256 B) aligned
+    cur = (cur + 63) & ~(size_t)63;
+    size_t o = cur;
+    cur += n;
+    return o;
+  }
+};
+
+void plan_bn(Arena& a, BNRef& bn, double count) {
+  bn.count = count;
+  const size_t C = bn.C;
+  bn.scale = a.f(C); bn.shift = a.f(C); bn.mean = a.f(C); bn.invstd = a.f(C);
+  bn.P = a.f(C); bn.Q = a.f(C); bn.R = a.f(C);
+}
+
+}  // namespace
+
+static inline int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+
+size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
+  const mmvqa_model_desc& d = e->d;
+  if (B <= 0 || T <= 0 || T > 128 || T > d.max_pos || T <= d.num_vis) {
+    mmvqa_set_error(MMVQA_ERR_ARG, "plan: bad B=%d T=%d (max_pos %d, num_vis %d, T<=128)", B, T, d.max_pos, d.num_vis);
+    return 0;
+  }
+  e->B = B; e->T = T; e->IH = IH; e->IW = IW;
+  Arena a;
+  const int H = d.hidden;
+  const size_t M = (size_t)B * T;
+  // ---- backbone
+  e->SH = conv_out(IH, 7, 2, 3); e->SW = conv_out(IW, 7, 2, 3);
+  e->PH = conv_out(e->SH, 3, 2, 1); e->PW = conv_out(e->SW, 3, 2, 1);
+  const int w = d.resnet_width;
+  const size_t M0 = (size_t)B * e->SH * e->SW;
+  e->z0 = a.f(M0 * w);
+  plan_bn(a, e->stem_bn, (double)M0);
+  e->p0 = a.f((size_t)B * e->PH * e->PW * w);
+  e->pool_idx = a.f(((size_t)B * e->PH * e->PW * w + 3) / 4);
+  int h = e->PH, wd = e->PW;
+  size_t max_io = M0 * w, max_mid = 0, max_tapM = M0;
+  for (auto& blk : e->blocks) {
+    blk.N = B; blk.H = h; blk.W = wd;
+    blk.OH = conv_out(h, 3, blk.c2.stride, 1); blk.OW = conv_out(wd, 3, blk.c2.stride, 1);
+    const size_t Min = (size_t)B * h * wd, Mout = (size_t)B * blk.OH * blk.OW;
+    blk.z1 = a.f(Min * blk.c1.Cout);
+    blk.z2 = a.f(Mout * blk.c2.Cout);
+    blk.z3 = a.f(Mout * blk.c3.Cout);
+    blk.out = a.f(Mout * blk.c3.Cout);
+    plan_bn(a, blk.b1, (double)Min);
+    plan_bn(a, blk.b2, (double)Mout);
+    plan_bn(a, blk.b3, (double)Mout);
+    if (blk.has_ds) { blk.zd = a.f(Mout * blk.cd.Cout); plan_bn(a, blk.bd, (double)Mout); }
+    max_io = std::max(max_io, std::max(Min * blk.c1.Cin, Mout * blk.c3.Cout));
+    max_mid = std::max(max_mid, std::max(Min * blk.c1.Cout, Mout * blk.c2.Cout));
+    h = blk.OH; wd = blk.OW;
+  }
+  // taps: k=0..3 on the outputs of layer4..layer1, k=4 on the stem
+  for (int k = 0; k < 4; ++k) {
+    const BlockRef& blk = e->blocks[e->layer_end[3 - k]];
+    e->taps[k].HW = blk.OH * blk.OW;
+    e->taps[k].M = (long)B * blk.OH * blk.OW;
+  }
+  e->taps[4].HW = e->SH * e->SW;
+  e->taps[4].M = (long)M0;
+  for (int k = 0; k < 5; ++k) {
+    max_tapM = std::max(max_tapM, (size_t)e->taps[k].M);
+    e->tapgrad[k] = a.f((size_t)e->taps[k].M * e->taps[k].C);
+  }
+  e->vis = a.f((size_t)5 * B * H);
+  e->dvis = a.f((size_t)5 * B * H);
+  e->du = a.f(max_tapM * H);
+  for (int i = 0; i < 3; ++i) e->gbuf[i] = a.f(max_io);
+  e->g1buf = a.f(max_mid);
+  e->g2buf = a.f(max_mid);
+  e->dstmp = a.f(max_io);
+  // ---- embeddings / encoder
+  e->emb_out = a.f(M * H); e->emb_xhat = a.f(M * H); e->emb_rstd = a.f(M);
+  if (d.encoder == 0) {
+    for (auto& L : e->bert) {
+      L.xn1 = a.f(M * H); L.mean1 = a.f(M); L.rstd1 = a.f(M);
+      L.qkvo = a.f(M * 3 * H); L.probs = a.f((size_t)B * d.heads * T * T); L.ctx = a.f(M * H);
+      L.y = a.f(M * H); L.xn2 = a.f(M * H); L.mean2 = a.f(M); L.rstd2 = a.f(M);
+      L.pre1 = a.f(M * 4 * H); L.h1 = a.f(M * 4 * H); L.z = a.f(M * H);
+    }
+  } else {
+    for (auto& L : e->rf) {
+      L.kqvo = a.f(M * 3 * H); L.probs = a.f((size_t)B * 8 * T * T); L.prev = a.f((size_t)B * T * T * 8);
+      L.res = a.f(M * H); L.s1 = a.f(M * H); L.x1 = a.f(M * H); L.mean1 = a.f(M); L.rstd1 = a.f(M);
+      L.pre = a.f(M * 4 * H); L.hact = a.f(M * 4 * H); L.s2 = a.f(M * H); L.x2 = a.f(M * H);
+      L.mean2 = a.f(M); L.rstd2 = a.f(M);
+    }
+  }
+  // ---- heads
+  const size_t HM = d.head_kind == 0 ? M : (size_t)B;
+  e->hd_pool = a.f((size_t)B * H);
+  e->hd_upre = a.f(HM * H); e->hd_u = a.f(HM * H); e->hd_c0 = a.f(HM * H); e->hd_c1 = a.f(HM * H);
+  e->hd_mean = a.f(HM); e->hd_rstd = a.f(HM);
+  if (d.supcon) {
+    e->sc_pool = a.f((size_t)B * H); e->sc_pre = a.f((size_t)B * H); e->sc_a = a.f((size_t)B * H);
+    e->sc_f = a.f((size_t)B * d.feat_dim); e->sc_nrm = a.f(B);
+  }
+  // ---- backward scratch
+  e->t_a = a.f(M * H); e->t_b = a.f(M * H); e->t_c = a.f(M * H); e->t_d = a.f(M * H);
+  e->t_big = a.f(M * 4 * H);
+  e->t_dprev[0] = a.f((size_t)B * T * T * 8); e->t_dprev[1] = a.f((size_t)B * T * T * 8);
+  // ---- BatchNorm statistic zones (doubles): [fwd of every BN][bwd of every BN]
+  e->statzone = a.f(0);
+  size_t sd = 0;  // in doubles
+  auto take = [&](BNRef& bn, bool bwd) {
+    (bwd ? bn.stat_b : bn.stat_f) = sd;
+    sd += (size_t)MMVQA_STAT_SLOTS * bn.C * 2;
+  };
+  take(e->stem_bn, false);
+  for (auto& blk : e->blocks) { take(blk.b1, false); take(blk.b2, false); take(blk.b3, false); if (blk.has_ds) take(blk.bd, false); }
+  const size_t half = sd;
+  take(e->stem_bn, true);
+  for (auto& blk : e->blocks) { take(blk.b1, true); take(blk.b2, true); take(blk.b3, true); if (blk.has_ds) take(blk.bd, true); }
+  if (sd != 2 * half) { mmvqa_set_error(MMVQA_ERR_STATE, "plan: stat zone mismatch"); return 0; }
+  e->statzone_floats = sd * 2;
+  a.f(e->statzone_floats);
+  e->ws_floats = (a.cur + 63) & ~(size_t)63;
+  e->planned = true;
+  e->bound = false;
+  return e->ws_floats * sizeof(float);
+}
+
+// --------------------------------------------------------------------------- launch helpers
+#define WS(off) (e->ws + (off))
+#define PRM(off) (e->params + (off))
+#define GRD(off) (e->grads + (off))
+static inline double* stat_ptr(mmvqa_engine* e, size_t doff) {
+  return reinterpret_cast<double*>(e->ws + e->statzone) + doff;
+}
+
+static int prof_begin(mmvqa_engine* e, hipStream_t st, int cls, double flops) {
+  if (!e->prof_on) return MMVQA_OK;
+  mmvqa_engine::ProfRec r;
+  HIP_CHECK_RET(hipEventCreate(&r.a));
+  HIP_CHECK_RET(hipEventCreate(&r.b));
+  r.cls = cls; r.flops = flops;
+  HIP_CHECK_RET(hipEventRecord(r.a, st));
+  e->prof.push_back(r);
+  return MMVQA_OK;
+}
+static int prof_end(mmvqa_engine* e, hipStream_t st) {
+  if (!e->prof_on) return MMVQA_OK;
+  HIP_CHECK_RET(hipEventRecord(e->prof.back().b, st));
+  return MMVQA_OK;
+}
+#define RUN(cls, flops, call)          \
+  do {                                 \
+    TRY(prof_begin(e, st, cls, flops)); \
+    TRY(call);                         \
+    TRY(prof_end(e, st));              \
+  } while (0)
+
+static GemmParams gp_linear_geom() {
+  GemmParams g;
+  memset(&g, 0, sizeof(g));
+  g.g_SH = g.g_SW = g.g_OH = g.g_OW = 1;
+  g.g_KH = g.g_KW = 1; g.g_stride = 1; g.g_pad = 0;
+  return g;
+}
+
+struct EpiOpt {
+  const float* R = nullptr; int r_ld = 0;
+  const float* Mk = nullptr; int mk_ld = 0; const float* mk_s = nullptr; const float* mk_b = nullptr;
+  BNRef* st1 = nullptr; const float* Z1 = nullptr;
+  BNRef* st2 = nullptr; const float* Z2 = nullptr;
+};
+
+static void apply_epi(mmvqa_engine* e, GemmParams& g, const EpiOpt& o) {
+  g.R = o.R; g.r_ld = o.r_ld;
+  g.Mk = o.Mk; g.mk_ld = o.mk_ld; g.mk_s = o.mk_s; g.mk_b = o.mk_b;
+  if (o.st1) {
+    g.stat1 = stat_ptr(e, o.st1->stat_b); g.stat_bwd = 1;
+    g.Z1 = o.Z1; g.z1_ld = o.st1->C; g.mean1 = WS(o.st1->mean); g.invstd1 = WS(o.st1->invstd);
+  }
+  if (o.st2) {
+    g.stat2 = stat_ptr(e, o.st2->stat_b);
+    g.Z2 = o.Z2; g.z2_ld = o.st2->C; g.mean2 = WS(o.st2->mean); g.invstd2 = WS(o.st2->invstd);
+  }
+}
+
+// y[M,out] = act(x[M,in] W^T + b) (+dropout) (+R)
+static int lin_fwd(mmvqa_engine* e, hipStream_t st, const float* x, int x_ld, long M, const LinRef& L, float* y,
+                   int y_ld, int act, float* pre, float drop_p, uint32_t seed, const float* R, int r_ld) {
+  GemmParams g = gp_linear_geom();
+  g.M = (int)M; g.N = L.out; g.K = L.in;
+  g.A = x; g.a_ld = x_ld; g.g_Cs = L.in;
+  g.B = PRM(L.w); g.b_ld = L.in;
+  g.C = y; g.c_ld = y_ld; g.Cpre = pre;
+  g.bias = L.b >= 0 ? PRM(L.b) : nullptr;
+  g.act = act; g.drop_p = drop_p; g.drop_seed = seed; g.R = R; g.r_ld = r_ld;
+  RUN(PROF_IGEMM, 2.0 * M * L.out * L.in, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
+  return MMVQA_OK;
+}
+
+// dx[M,in] = dy[M,out] W  (optionally * act'(Pre), + R, column sums for the upstream bias)
+static int lin_dgrad(mmvqa_engine* e, hipStream_t st, const float* dy, int dy_ld, long M, const LinRef& L, float* dx,
+                     int dx_ld, int dact, const float* Pre, int pre_ld, float* colsum, const float* R, int r_ld) {
+  GemmParams g = gp_linear_geom();
+  g.M = (int)M; g.N = L.in; g.K = L.out;
+  g.A = dy; g.a_ld = dy_ld; g.g_Cs = L.out;
+  g.B = PRM(L.w); g.b_ld = L.in; g.b_tapstride = 0;
+  g.C = dx; g.c_ld = dx_ld;
+  g.dact = dact; g.Pre = Pre; g.pre_ld = pre_ld; g.colsum = colsum; g.R = R; g.r_ld = r_ld;
+  RUN(PROF_IGEMM, 2.0 * M * L.out * L.in, mmvqa_launch_igemm(g, KIND_DGRAD, 0, 0, st));
+  return MMVQA_OK;
+}
+
+// dW[out,in] += dy^T x ; db[out] += colsum(dy)
+static int lin_wgrad(mmvqa_engine* e, hipStream_t st, const float* dy, int dy_ld, const float* x, int x_ld, long M,
+                     const LinRef& L, bool bias_from_colsum) {
+  GemmParams g = gp_linear_geom();
+  g.M = L.out; g.N = L.in; g.K = (int)M;
+  g.A = dy; g.a_ld = dy_ld;
+  g.B = x; g.b_ld = x_ld; g.g_Cs = L.in;
+  g.C = GRD(L.w); g.c_ld = L.in; g.c_atomic = 1;
+  RUN(PROF_IGEMM, 2.0 * M * L.out * L.in, mmvqa_launch_igemm(g, KIND_WGRAD, 0, 0, st));
+  if (bias_from_colsum && L.b >= 0) RUN(PROF_OTHER, 0, k_colsum(st, dy, dy_ld, (int)M, L.out, GRD(L.b)));
+  return MMVQA_OK;
+}
+
+static int ln_fwd(mmvqa_engine* e, hipStream_t st, const float* x, const LNRef& ln, float* y, float* mean,
+                  float* rstd, long rows, float eps) {
+  RUN(PROF_OTHER, 0, k_layernorm_fwd(st, x, nullptr, PRM(ln.g), PRM(ln.b), y, nullptr, mean, rstd, (int)rows,
+                                     e->d.hidden, eps));
+  return MMVQA_OK;
+}
+static int ln_bwd(mmvqa_engine* e, hipStream_t st, const float* dy, const float* x, const LNRef& ln,
+                  const float* mean, const float* rstd, const float* dres, float* dx, long rows) {
+  RUN(PROF_OTHER, 0, k_layernorm_bwd(st, dy, x, PRM(ln.g), mean, rstd, dres, dx, GRD(ln.g), GRD(ln.b), (int)rows,
+                                     e->d.hidden));
+  return MMVQA_OK;
+}
+
+// --------------------------------------------------------------------------- convolution helpers
+static void conv_geom(GemmParams& g, const ConvRef& c, int H, int W, int OH, int OW) {
+  g.g_KH = g.g_KW = c.KH; g.g_stride = c.stride; g.g_pad = c.pad;
+  (void)H; (void)W; (void)OH; (void)OW;
+}
+
+static int bn_coef_fwd(mmvqa_engine* e, hipStream_t st, BNRef& bn) {
+  RUN(PROF_OTHER, 0,
+      k_bn_coef_fwd(st, stat_ptr(e, bn.stat_f), bn.C, bn.count, 1e-5f, PRM(bn.gamma), PRM(bn.beta),
+                    e->bufs + bn.rmean, e->bufs + bn.rvar, e->nbt + bn.nbt, 0.1f, bn.reps, e->training,
+                    WS(bn.scale), WS(bn.shift), WS(bn.mean), WS(bn.invstd)));
+  return MMVQA_OK;
+}
+static int bn_coef_bwd(mmvqa_engine* e, hipStream_t st, BNRef& bn) {
+  RUN(PROF_OTHER, 0,
+      k_bn_coef_bwd(st, stat_ptr(e, bn.stat_b), bn.C, bn.count, PRM(bn.gamma), WS(bn.mean), WS(bn.invstd),
+                    e->training, WS(bn.P), WS(bn.Q), WS(bn.R), GRD(bn.gamma), GRD(bn.beta)));
+  return MMVQA_OK;
+}
+
+// z = conv(x) with x optionally = relu(bn_in(x_raw)); accumulates the batch statistics of z
+static int conv_fwd(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const float* x, const BNRef* bn_in, int N,
+                    int H, int W, int OH, int OW, float* z, BNRef& bn_out) {
+  GemmParams g;
+  memset(&g, 0, sizeof(g));
+  g.M = N * OH * OW; g.N = c.Cout; g.K = c.KH * c.KH * c.Cin;
+  g.A = x; g.a_ld = c.Cin;
+  if (bn_in) { g.a_pro = PRO_AFFINE_RELU; g.a_c0 = WS(bn_in->scale); g.a_c1 = WS(bn_in->shift); }
+  g.g_SH = H; g.g_SW = W; g.g_Cs = c.Cin; g.g_OH = OH; g.g_OW = OW;
+  conv_geom(g, c, H, W, OH, OW);
+  g.B = PRM(c.w); g.b_ld = g.K;
+  g.C = z; g.c_ld = c.Cout;
+  if (e->training) { g.stat1 = stat_ptr(e, bn_out.stat_f); g.stat_bwd = 0; }
+  RUN(PROF_IGEMM, 2.0 * g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
+  return bn_coef_fwd(e, st, bn_out);
+}
+
+// dW += dz^T * x_gathered with dz = P*G + Q*z + R (BatchNorm backward of bn_out), x optionally relu(bn_in(.))
+static int conv_wgrad(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const float* G, const float* z,
+                      const BNRef& bn_out, const float* x, const BNRef* bn_in, int N, int H, int W, int OH, int OW) {
+  GemmParams g;
+  memset(&g, 0, sizeof(g));
+  g.M = c.Cout; g.N = c.KH * c.KH * c.Cin; g.K = N * OH * OW;
+  g.A = G; g.A2 = z; g.a_ld = c.Cout; g.a_pro = PRO_DZ;
+  g.a_c0 = WS(bn_out.P); g.a_c1 = WS(bn_out.Q); g.a_c2 = WS(bn_out.R);
+  g.B = x; g.b_ld = c.Cin;
+  if (bn_in) { g.b_pro = PRO_AFFINE_RELU; g.b_c0 = WS(bn_in->scale); g.b_c1 = WS(bn_in->shift); }
+  g.g_SH = H; g.g_SW = W; g.g_Cs = c.Cin; g.g_OH = OH; g.g_OW = OW;
+  conv_geom(g, c, H, W, OH, OW);
+  g.C = GRD(c.w); g.c_ld = g.N; g.c_atomic = 1;
+  RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_WGRAD, 0, 0, st));
+  return MMVQA_OK;
+}
+
+// dx[N,H,W,Cin] = conv_transpose(dz, W) with dz as above; epilogue options in `o`
+static int conv_dgrad(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const float* G, const float* z,
+                      const BNRef& bn_out, int N, int H, int W, int OH, int OW, float* dx, const EpiOpt& o) {
+  GemmParams g;
+  memset(&g, 0, sizeof(g));
+  g.M = N * H * W; g.N = c.Cin; g.K = c.KH * c.KH * c.Cout;
+  g.A = G; g.A2 = z; g.a_ld = c.Cout; g.a_pro = PRO_DZ;
+  g.a_c0 = WS(bn_out.P); g.a_c1 = WS(bn_out.Q); g.a_c2 = WS(bn_out.R);
+  g.g_SH = OH; g.g_SW = OW; g.g_Cs = c.Cout; g.g_OH = H; g.g_OW = W;
+  conv_geom(g, c, H, W, OH, OW);
+  g.B = PRM(c.w); g.b_ld = c.KH * c.KH * c.Cin; g.b_tapstride = c.Cin;
+  g.C = dx; g.c_ld = c.Cin;
+  apply_epi(e, g, o);
+  RUN(PROF_IGEMM, 2.0 * (double)N * OH * OW * c.Cout * c.KH * c.KH * c.Cin,
+      mmvqa_launch_igemm(g, KIND_DGRAD, 0, 0, st));
+  return MMVQA_OK;
+}
+
+// --------------------------------------------------------------------------- taps (models/image_encoding.py:53-62,72-86)
+static int tap_act(const mmvqa_engine* e) { return e->d.use_relu ? ACT_RELU : ACT_SERF; }
+
+static int tap_fwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, const BNRef* bn_in) {
+  const TapRef& t = e->taps[k];
+  GemmParams g = gp_linear_geom();
+  g.M = (int)t.M; g.N = e->d.hidden; g.K = t.C;
+  g.A = fmap; g.a_ld = t.C; g.g_Cs = t.C;
+  if (bn_in) { g.a_pro = PRO_AFFINE_RELU; g.a_c0 = WS(bn_in->scale); g.a_c1 = WS(bn_in->shift); }
+  g.B = PRM(t.w); g.b_ld = t.C;
+  g.epi_mode = EPI_TAP_FWD; g.act = tap_act(e); g.tap_HW = t.HW;
+  g.tap_out = WS(e->vis) + (size_t)k * e->B * e->d.hidden;
+  g.C = g.tap_out; g.c_ld = g.N;  // unused by this epilogue
+  RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
+  return MMVQA_OK;
+}
+
+// backward of one tap: du (recompute), dW_tap, and the gradient wrt the feature map (T_k or masked G)
+static int tap_bwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, const BNRef* bn_in, float* dfmap,
+                   const EpiOpt& o) {
+  const TapRef& t = e->taps[k];
+  const int Hd = e->d.hidden;
+  GemmParams g = gp_linear_geom();
+  g.M = (int)t.M; g.N = Hd; g.K = t.C;
+  g.A = fmap; g.a_ld = t.C; g.g_Cs = t.C;
+  if (bn_in) { g.a_pro = PRO_AFFINE_RELU; g.a_c0 = WS(bn_in->scale); g.a_c1 = WS(bn_in->shift); }
+  g.B = PRM(t.w); g.b_ld = t.C;
+  g.epi_mode = EPI_TAP_BWD; g.act = tap_act(e); g.tap_HW = t.HW;
+  g.tap_dv = WS(e->dvis) + (size_t)k * e->B * Hd;
+  g.C = WS(e->du); g.c_ld = Hd;
+  RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
+  // dW_tap[Hd][C] += du^T fmap
+  GemmParams w = gp_linear_geom();
+  w.M = Hd; w.N = t.C; w.K = (int)t.M;
+  w.A = WS(e->du); w.a_ld = Hd;
+  w.B = fmap; w.b_ld = t.C; w.g_Cs = t.C;
+  if (bn_in) { w.b_pro = PRO_AFFINE_RELU; w.b_c0 = WS(bn_in->scale); w.b_c1 = WS(bn_in->shift); }
+  w.C = GRD(t.w); w.c_ld = t.C; w.c_atomic = 1;
+  RUN(PROF_IGEMM, 2.0 * (double)w.M * w.N * w.K, mmvqa_launch_igemm(w, KIND_WGRAD, 0, 0, st));
+  // dfmap[M][C] = du W_tap
+  GemmParams dg = gp_linear_geom();
+  dg.M = (int)t.M; dg.N = t.C; dg.K = Hd;
+  dg.A = WS(e->du); dg.a_ld = Hd; dg.g_Cs = Hd;
+  dg.B = PRM(t.w); dg.b_ld = t.C;
+  dg.C = dfmap; dg.c_ld = t.C;
+  apply_epi(e, dg, o);
+  RUN(PROF_IGEMM, 2.0 * (double)dg.M * dg.N * dg.K, mmvqa_launch_igemm(dg, KIND_DGRAD, 0, 0, st));
+  return MMVQA_OK;
+}
+
+// --------------------------------------------------------------------------- ResNet forward / backward
+static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
+  const mmvqa_model_desc& d = e->d;
+  const int B = e->B, w = d.resnet_width;
+  if (e->training)
+    HIP_CHECK_RET(hipMemsetAsync(stat_ptr(e, 0), 0, e->statzone_floats / 2 * sizeof(float), st));
+  HIP_CHECK_RET(hipMemsetAsync(WS(e->vis), 0, (size_t)5 * B * d.hidden * sizeof(float), st));
+  {  // stem 7x7/2 on the NCHW image
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = B * e->SH * e->SW; g.N = w; g.K = 147;
+    g.A = e->img; g.g_nchw = 1;
+    g.g_SH = e->IH; g.g_SW = e->IW; g.g_Cs = 3; g.g_OH = e->SH; g.g_OW = e->SW;
+    g.g_KH = g.g_KW = 7; g.g_stride = 2; g.g_pad = 3;
+    g.B = PRM(e->stem_conv.w); g.b_ld = 147;
+    g.C = WS(e->z0); g.c_ld = w;
+    if (e->training) g.stat1 = stat_ptr(e, e->stem_bn.stat_f);
+    RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 1, 0, st));
+    TRY(bn_coef_fwd(e, st, e->stem_bn));
+  }
+  TRY(tap_fwd(e, st, 4, WS(e->z0), &e->stem_bn));
+  RUN(PROF_OTHER, 0, k_maxpool_fwd(st, WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), WS(e->p0),
+                                   reinterpret_cast<unsigned char*>(WS(e->pool_idx)), B, e->SH, e->SW, w, e->PH,
+                                   e->PW));
+  const float* x = WS(e->p0);
+  int layer = 0;
+  for (size_t i = 0; i < e->blocks.size(); ++i) {
+    BlockRef& b = e->blocks[i];
+    TRY(conv_fwd(e, st, b.c1, x, nullptr, B, b.H, b.W, b.H, b.W, WS(b.z1), b.b1));
+    TRY(conv_fwd(e, st, b.c2, WS(b.z1), &b.b1, B, b.H, b.W, b.OH, b.OW, WS(b.z2), b.b2));
+    TRY(conv_fwd(e, st, b.c3, WS(b.z2), &b.b2, B, b.OH, b.OW, b.OH, b.OW, WS(b.z3), b.b3));
+    const long rows = (long)B * b.OH * b.OW;
+    if (b.has_ds) {
+      TRY(conv_fwd(e, st, b.cd, x, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.zd), b.bd));
+      RUN(PROF_OTHER, 0, k_bn_add_relu(st, WS(b.z3), WS(b.b3.scale), WS(b.b3.shift), WS(b.zd), WS(b.bd.scale),
+                                       WS(b.bd.shift), WS(b.out), rows, b.c3.Cout));
+    } else {
+      RUN(PROF_OTHER, 0, k_bn_add_relu(st, WS(b.z3), WS(b.b3.scale), WS(b.b3.shift), x, nullptr, nullptr,
+                                       WS(b.out), rows, b.c3.Cout));
+    }
+    x = WS(b.out);
+    if ((int)i == e->layer_end[layer]) {
+      TRY(tap_fwd(e, st, 3 - layer, x, nullptr));
+      ++layer;
+    }
+  }
+  return MMVQA_OK;
+}
+
+static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
+  const int B = e->B, w = e->d.resnet_width;
+  HIP_CHECK_RET(hipMemsetAsync(stat_ptr(e, 0) + e->statzone_floats / 4, 0,
+                               e->statzone_floats / 2 * sizeof(float), st));
+  const int nb = (int)e->blocks.size();
+  // taps on layer1..3 and the stem produce side gradients T_k; the layer4 tap starts the main chain
+  for (int k = 1; k <= 3; ++k) {
+    const BlockRef& blk = e->blocks[e->layer_end[3 - k]];
+    TRY(tap_bwd(e, st, k, WS(blk.out), nullptr, WS(e->tapgrad[k]), EpiOpt()));
+  }
+  TRY(tap_bwd(e, st, 4, WS(e->z0), &e->stem_bn, WS(e->tapgrad[4]), EpiOpt()));
+  int cur = 0;
+  {
+    BlockRef& last = e->blocks[nb - 1];
+    EpiOpt o;
+    o.Mk = WS(last.out); o.mk_ld = last.c3.Cout;
+    o.st1 = &last.b3; o.Z1 = WS(last.z3);
+    if (last.has_ds) { o.st2 = &last.bd; o.Z2 = WS(last.zd); }
+    TRY(tap_bwd(e, st, 0, WS(last.out), nullptr, WS(e->gbuf[cur]), o));
+  }
+  for (int i = nb - 1; i >= 0; --i) {
+    BlockRef& b = e->blocks[i];
+    const float* G = WS(e->gbuf[cur]);
+    const float* x = i == 0 ? WS(e->p0) : WS(e->blocks[i - 1].out);
+    float* Gprev = WS(e->gbuf[cur ^ 1]);
+    // side gradient arriving at this block's input from a tap (only where the previous block ends a layer)
+    const float* extra = nullptr;
+    for (int l = 0; l < 3; ++l)
+      if (i - 1 == e->layer_end[l]) extra = WS(e->tapgrad[3 - l]);
+    // conv3 / bn3
+    TRY(bn_coef_bwd(e, st, b.b3));
+    TRY(conv_wgrad(e, st, b.c3, G, WS(b.z3), b.b3, WS(b.z2), &b.b2, B, b.OH, b.OW, b.OH, b.OW));
+    {
+      EpiOpt o;
+      o.Mk = WS(b.z2); o.mk_ld = b.c2.Cout; o.mk_s = WS(b.b2.scale); o.mk_b = WS(b.b2.shift);
+      o.st1 = &b.b2; o.Z1 = WS(b.z2);
+      TRY(conv_dgrad(e, st, b.c3, G, WS(b.z3), b.b3, B, b.OH, b.OW, b.OH, b.OW, WS(e->g2buf), o));
+    }
+    // conv2 / bn2
+    TRY(bn_coef_bwd(e, st, b.b2));
+    TRY(conv_wgrad(e, st, b.c2, WS(e->g2buf), WS(b.z2), b.b2, WS(b.z1), &b.b1, B, b.H, b.W, b.OH, b.OW));
+    {
+      EpiOpt o;
+      o.Mk = WS(b.z1); o.mk_ld = b.c1.Cout; o.mk_s = WS(b.b1.scale); o.mk_b = WS(b.b1.shift);
+      o.st1 = &b.b1; o.Z1 = WS(b.z1);
+      TRY(conv_dgrad(e, st, b.c2, WS(e->g2buf), WS(b.z2), b.b2, B, b.H, b.W, b.OH, b.OW, WS(e->g1buf), o));
+    }
+    // conv1 / bn1
+    TRY(bn_coef_bwd(e, st, b.b1));
+    TRY(conv_wgrad(e, st, b.c1, WS(e->g1buf), WS(b.z1), b.b1, x, nullptr, B, b.H, b.W, b.H, b.W));
+    // gradient wrt the block input: conv1 path + identity/downsample path (+ tap side gradient)
+    EpiOpt o;
+    if (i > 0) {
+      BlockRef& pb = e->blocks[i - 1];
+      o.Mk = x; o.mk_ld = b.c1.Cin;
+      o.st1 = &pb.b3; o.Z1 = WS(pb.z3);
+      if (pb.has_ds) { o.st2 = &pb.bd; o.Z2 = WS(pb.zd); }
+    }
+    if (b.has_ds) {
+      TRY(bn_coef_bwd(e, st, b.bd));
+      TRY(conv_wgrad(e, st, b.cd, G, WS(b.zd), b.bd, x, nullptr, B, b.H, b.W, b.OH, b.OW));
+      EpiOpt od;
+      od.R = extra; od.r_ld = b.cd.Cin;
+      TRY(conv_dgrad(e, st, b.cd, G, WS(b.zd), b.bd, B, b.H, b.W, b.OH, b.OW, WS(e->dstmp), od));
+      o.R = WS(e->dstmp); o.r_ld = b.c1.Cin;
+    } else {
+      if (extra) return mmvqa_set_error(MMVQA_ERR_STATE, "resnet_backward: tap gradient without downsample");
+      o.R = G; o.r_ld = b.c1.Cin;
+    }
+    TRY(conv_dgrad(e, st, b.c1, WS(e->g1buf), WS(b.z1), b.b1, B, b.H, b.W, b.H, b.W, Gprev, o));
+    cur ^= 1;
+  }
+  // stem: max-pool backward + stem-tap gradient + ReLU mask + BN statistics, then the 7x7 weight gradient
+  float* g0 = WS(e->gbuf[cur ^ 1]);
+  RUN(PROF_OTHER, 0,
+      k_maxpool_bwd(st, WS(e->gbuf[cur]), reinterpret_cast<unsigned char*>(WS(e->pool_idx)), WS(e->tapgrad[4]),
+                    WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), WS(e->stem_bn.mean),
+                    WS(e->stem_bn.invstd), g0, stat_ptr(e, e->stem_bn.stat_b), B, e->SH, e->SW, w, e->PH, e->PW));
+  TRY(bn_coef_bwd(e, st, e->stem_bn));
+  {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = w; g.N = 147; g.K = B * e->SH * e->SW;
+    g.A = g0; g.A2 = WS(e->z0); g.a_ld = w; g.a_pro = PRO_DZ;
+    g.a_c0 = WS(e->stem_bn.P); g.a_c1 = WS(e->stem_bn.Q); g.a_c2 = WS(e->stem_bn.R);
+    g.B = e->img; g.g_nchw = 1;
+    g.g_SH = e->IH; g.g_SW = e->IW; g.g_Cs = 3; g.g_OH = e->SH; g.g_OW = e->SW;
+    g.g_KH = g.g_KW = 7; g.g_stride = 2; g.g_pad = 3;
+    g.C = GRD(e->stem_conv.w); g.c_ld = 147; g.c_atomic = 1;
+    RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_WGRAD, 1, 0, st));
+  }
+  return MMVQA_OK;
+}
+
+// --------------------------------------------------------------------------- encoders
+static inline uint32_t site_seed(const mmvqa_engine* e, int layer, int site) {
+  return e->seed + 0x9E3779B9u * (uint32_t)(layer * 8 + site + 1);
+}
+
+static int attn_call(mmvqa_engine* e, hipStream_t st, AttnParams& a, int head_dim, int bwd) {
+  const double fl = (bwd ? 10.0 : 4.0) * (double)e->B * a.heads * e->T * e->T * head_dim;
+  RUN(PROF_ATTN, fl, mmvqa_launch_attention(a, head_dim, bwd, st));
+  return MMVQA_OK;
+}
+
+// models/transformer.py:75-86 (pre-LN, norm1 for both sub-layers, shared by all layers)
+static int bert_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, const float** x_out) {
+  const mmvqa_model_desc& d = e->d;
+  const int H = d.hidden;
+  const long M = (long)e->B * e->T;
+  const float p = e->training ? d.p_drop : 0.f;
+  const float* x = x_in;
+  for (int i = 0; i < d.n_layers; ++i) {
+    BertLayerRef& L = e->bert[i];
+    TRY(ln_fwd(e, st, x, e->norm1, WS(L.xn1), WS(L.mean1), WS(L.rstd1), M, 1e-12f));
+    TRY(lin_fwd(e, st, WS(L.xn1), H, M, L.qkv, WS(L.qkvo), 3 * H, ACT_NONE, nullptr, 0.f, 0, nullptr, 0));
+    AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = WS(L.qkvo); a.k = a.q + H; a.v = a.q + 2 * H;
+    a.row_stride = 3 * H; a.head_stride = H / d.heads;
+    a.out = WS(L.ctx); a.out_row_stride = H; a.out_head_stride = H / d.heads;
+    a.mask = e->mask; a.mask_on_query = 0; a.probs = WS(L.probs);
+    a.B = e->B; a.T = e->T; a.heads = d.heads; a.sqrt_d = sqrtf((float)(H / d.heads));
+    a.drop_p = p; a.seed = site_seed(e, i, 0);
+    TRY(attn_call(e, st, a, H / d.heads, 0));
+    TRY(lin_fwd(e, st, WS(L.ctx), H, M, L.proj, WS(L.y), H, ACT_NONE, nullptr, p, site_seed(e, i, 1), x, H));
+    TRY(ln_fwd(e, st, WS(L.y), e->norm1, WS(L.xn2), WS(L.mean2), WS(L.rstd2), M, 1e-12f));
+    TRY(lin_fwd(e, st, WS(L.xn2), H, M, L.fc1, WS(L.h1), 4 * H, ACT_GELU, WS(L.pre1), 0.f, 0, nullptr, 0));
+    TRY(lin_fwd(e, st, WS(L.h1), 4 * H, M, L.fc2, WS(L.z), H, ACT_NONE, nullptr, p, site_seed(e, i, 2), WS(L.y), H));
+    x = WS(L.z);
+  }
+  *x_out = x;
+  return MMVQA_OK;
+}
+
+// dz (in t_a) -> dx (left in t_a)
+static int bert_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
+  const mmvqa_model_desc& d = e->d;
+  const int H = d.hidden;
+  const long M = (long)e->B * e->T;
+  const float p = e->training ? d.p_drop : 0.f;
+  float* dz = WS(e->t_a);
+  for (int i = d.n_layers - 1; i >= 0; --i) {
+    BertLayerRef& L = e->bert[i];
+    const float* x = i == 0 ? x_in : WS(e->bert[i - 1].z);
+    // FFN branch: z = y + drop(fc2(gelu(fc1(norm1(y)))))
+    const float* dzd = dz;
+    if (p > 0.f) {
+      RUN(PROF_OTHER, 0, k_dropout_copy(st, dz, WS(e->t_b), M * H, p, site_seed(e, i, 2)));
+      dzd = WS(e->t_b);
+    }
+    TRY(lin_wgrad(e, st, dzd, H, WS(L.h1), 4 * H, M, L.fc2, true));
+    TRY(lin_dgrad(e, st, dzd, H, M, L.fc2, WS(e->t_big), 4 * H, ACT_GELU, WS(L.pre1), 4 * H, GRD(L.fc1.b), nullptr, 0));
+    TRY(lin_wgrad(e, st, WS(e->t_big), 4 * H, WS(L.xn2), H, M, L.fc1, false));
+    TRY(lin_dgrad(e, st, WS(e->t_big), 4 * H, M, L.fc1, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0));
+    // dy = LN'(dxn2) + dz
+    TRY(ln_bwd(e, st, WS(e->t_c), WS(L.y), e->norm1, WS(L.mean2), WS(L.rstd2), dz, WS(e->t_d), M));
+    float* dy = WS(e->t_d);
+    // attention branch: y = x + drop(proj(attn(norm1(x))))
+    const float* dyd = dy;
+    if (p > 0.f) {
+      RUN(PROF_OTHER, 0, k_dropout_copy(st, dy, WS(e->t_b), M * H, p, site_seed(e, i, 1)));
+      dyd = WS(e->t_b);
+    }
+    TRY(lin_wgrad(e, st, dyd, H, WS(L.ctx), H, M, L.proj, true));
+    TRY(lin_dgrad(e, st, dyd, H, M, L.proj, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0));  // dctx
+    AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = WS(L.qkvo); a.k = a.q + H; a.v = a.q + 2 * H;
+    a.row_stride = 3 * H; a.head_stride = H / d.heads;
+    a.out_row_stride = H; a.out_head_stride = H / d.heads;
+    a.mask = e->mask; a.mask_on_query = 0; a.probs = WS(L.probs);
+    a.B = e->B; a.T = e->T; a.heads = d.heads; a.sqrt_d = sqrtf((float)(H / d.heads));
+    a.drop_p = p; a.seed = site_seed(e, i, 0);
+    a.dout = WS(e->t_c);
+    float* dqkv = WS(e->t_big);
+    a.dq = dqkv; a.dk = dqkv + H; a.dv = dqkv + 2 * H;
+    TRY(attn_call(e, st, a, H / d.heads, 1));
+    TRY(lin_wgrad(e, st, dqkv, 3 * H, WS(L.xn1), H, M, L.qkv, true));
+    TRY(lin_dgrad(e, st, dqkv, 3 * H, M, L.qkv, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0));  // dxn1
+    TRY(ln_bwd(e, st, WS(e->t_c), x, e->norm1, WS(L.mean1), WS(L.rstd1), dy, dz, M));
+  }
+  return MMVQA_OK;
+}
+
+// models/realformer.py:30-51 (post-LN, shared per-head kqv, residual scores, query-axis mask)
+static int rf_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, const float** x_out) {
+  const mmvqa_model_desc& d = e->d;
+  const int H = d.hidden, es = H / 8;
+  const long M = (long)e->B * e->T;
+  const float p = e->training ? d.p_rf_drop : 0.f;
+  const float* x = x_in;
+  for (int i = 0; i < d.n_layers; ++i) {
+    RFLayerRef& L = e->rf[i];
+    TRY(lin_fwd(e, st, x, es, M * 8, L.kqv, WS(L.kqvo), 3 * es, ACT_NONE, nullptr, 0.f, 0, nullptr, 0));
+    AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.k = WS(L.kqvo); a.q = a.k + es; a.v = a.k + 2 * es;
+    a.row_stride = 8 * 3 * es; a.head_stride = 3 * es;
+    a.out = WS(L.res); a.out_row_stride = H; a.out_head_stride = es;
+    a.mask = e->mask; a.mask_on_query = 1;
+    a.prev_in = i > 0 ? WS(e->rf[i - 1].prev) : nullptr;
+    a.prev_out = WS(L.prev); a.probs = WS(L.probs);
+    a.B = e->B; a.T = e->T; a.heads = 8; a.sqrt_d = sqrtf((float)es);
+    TRY(attn_call(e, st, a, es, 0));
+    // s1 = x + drop(proj(res)); x1 = ln1(s1)
+    TRY(lin_fwd(e, st, WS(L.res), H, M, L.proj, WS(L.s1), H, ACT_NONE, nullptr, p, site_seed(e, i, 1), x, H));
+    TRY(ln_fwd(e, st, WS(L.s1), L.ln1, WS(L.x1), WS(L.mean1), WS(L.rstd1), M, 1e-5f));
+    TRY(lin_fwd(e, st, WS(L.x1), H, M, L.ff0, WS(L.hact), 4 * H, ACT_SERF, WS(L.pre), 0.f, 0, nullptr, 0));
+    TRY(lin_fwd(e, st, WS(L.hact), 4 * H, M, L.ff2, WS(L.s2), H, ACT_NONE, nullptr, p, site_seed(e, i, 2), WS(L.x1), H));
+    TRY(ln_fwd(e, st, WS(L.s2), L.ln2, WS(L.x2), WS(L.mean2), WS(L.rstd2), M, 1e-5f));
+    x = WS(L.x2);
+  }
+  *x_out = x;
+  return MMVQA_OK;
+}
+
+static int rf_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
+  const mmvqa_model_desc& d = e->d;
+  const int H = d.hidden, es = H / 8;
+  const long M = (long)e->B * e->T;
+  const float p = e->training ? d.p_rf_drop : 0.f;
+  float* dx2 = WS(e->t_a);
+  for (int i = d.n_layers - 1; i >= 0; --i) {
+    RFLayerRef& L = e->rf[i];
+    const float* x = i == 0 ? x_in : WS(e->rf[i - 1].x2);
+    // x2 = ln2(s2), s2 = x1 + drop(ff2(serf(ff0(x1))))
+    TRY(ln_bwd(e, st, dx2, WS(L.s2), L.ln2, WS(L.mean2), WS(L.rstd2), nullptr, WS(e->t_d), M));
+    float* ds2 = WS(e->t_d);
+    const float* dff = ds2;
+    if (p > 0.f) {
+      RUN(PROF_OTHER, 0, k_dropout_copy(st, ds2, WS(e->t_b), M * H, p, site_seed(e, i, 2)));
+      dff = WS(e->t_b);
+    }
+    TRY(lin_wgrad(e, st, dff, H, WS(L.hact), 4 * H, M, L.ff2, true));
+    TRY(lin_dgrad(e, st, dff, H, M, L.ff2, WS(e->t_big), 4 * H, ACT_SERF, WS(L.pre), 4 * H, GRD(L.ff0.b), nullptr, 0));
+    TRY(lin_wgrad(e, st, WS(e->t_big), 4 * H, WS(L.x1), H, M, L.ff0, false));
+    TRY(lin_dgrad(e, st, WS(e->t_big), 4 * H, M, L.ff0, WS(e->t_c), H, 0, nullptr, 0, nullptr, ds2, H));  // dx1 total
+    // x1 = ln1(s1), s1 = x + drop(proj(res))
+    TRY(ln_bwd(e, st, WS(e->t_c), WS(L.s1), L.ln1, WS(L.mean1), WS(L.rstd1), nullptr, WS(e->t_d), M));
+    float* ds1 = WS(e->t_d);
+    const float* dr = ds1;
+    if (p > 0.f) {
+      RUN(PROF_OTHER, 0, k_dropout_copy(st, ds1, WS(e->t_b), M * H, p, site_seed(e, i, 1)));
+      dr = WS(e->t_b);
+    }
+    TRY(lin_wgrad(e, st, dr, H, WS(L.res), H, M, L.proj, false));
+    TRY(lin_dgrad(e, st, dr, H, M, L.proj, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0));  // dres
+    AttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.k = WS(L.kqvo); a.q = a.k + es; a.v = a.k + 2 * es;
+    a.row_stride = 8 * 3 * es; a.head_stride = 3 * es;
+    a.out_row_stride = H; a.out_head_stride = es;
+    a.mask = e->mask; a.mask_on_query = 1; a.probs = WS(L.probs);
+    a.B = e->B; a.T = e->T; a.heads = 8; a.sqrt_d = sqrtf((float)es);
+    a.dout = WS(e->t_c);
+    float* dkqv = WS(e->t_big);
+    a.dk = dkqv; a.dq = dkqv + es; a.dv = dkqv + 2 * es;
+    a.dprev_in = (i < d.n_layers - 1) ? WS(e->t_dprev[(i + 1) & 1]) : nullptr;
+    a.dprev_out = i > 0 ? WS(e->t_dprev[i & 1]) : nullptr;
+    TRY(attn_call(e, st, a, es, 1));
+    TRY(lin_wgrad(e, st, dkqv, 3 * es, x, es, M * 8, L.kqv, false));
+    TRY(lin_dgrad(e, st, dkqv, 3 * es, M * 8, L.kqv, dx2, es, 0, nullptr, 0, nullptr, ds1, es));  // dx total
+  }
+  return MMVQA_OK;
+}
+
+// --------------------------------------------------------------------------- heads (models/mmbert.py:150-167)
+static int heads_forward(mmvqa_engine* e, hipStream_t st, const float* h) {
+  const mmvqa_model_desc& d = e->d;
+  const int H = d.hidden;
+  const long M = (long)e->B * e->T;
+  const float* hin = h;
+  long HM = M;
+  if (d.head_kind == 1) {
+    RUN(PROF_OTHER, 0, k_meanpool_fwd(st, h, e->mask, WS(e->hd_pool), e->B, e->T, H));
+    hin = WS(e->hd_pool);
+    HM = e->B;
+  }
+  TRY(lin_fwd(e, st, hin, H, HM, e->fc1, WS(e->hd_u), H, ACT_SERF, WS(e->hd_upre), 0.f, 0, nullptr, 0));
+  TRY(lin_fwd(e, st, WS(e->hd_u), H, HM, e->cls0, WS(e->hd_c0), H, ACT_NONE, nullptr, 0.f, 0, nullptr, 0));
+  TRY(ln_fwd(e, st, WS(e->hd_c0), e->cls_ln, WS(e->hd_c1), WS(e->hd_mean), WS(e->hd_rstd), HM, 1e-12f));
+  TRY(lin_fwd(e, st, WS(e->hd_c1), H, HM, e->cls2, e->logits, e->logits_ld, ACT_NONE, nullptr, 0.f, 0, nullptr, 0));
+  if (d.supcon && e->feat) {
+    RUN(PROF_OTHER, 0, k_meanpool_fwd(st, h, e->mask, WS(e->sc_pool), e->B, e->T, H));
+    TRY(lin_fwd(e, st, WS(e->sc_pool), H, e->B, e->head0, WS(e->sc_a), H, ACT_SERF, WS(e->sc_pre), 0.f, 0, nullptr, 0));
+    TRY(lin_fwd(e, st, WS(e->sc_a), H, e->B, e->head2, WS(e->sc_f), d.feat_dim, ACT_NONE, nullptr, 0.f, 0, nullptr, 0));
+    RUN(PROF_OTHER, 0, k_l2norm_fwd(st, WS(e->sc_f), e->feat, WS(e->sc_nrm), e->B, d.feat_dim));
+  }
+  return MMVQA_OK;
+}
+
+// produces dh (gradient wrt the encoder output) in t_a
+static int heads_backward(mmvqa_engine* e, hipStream_t st, const float* h, const float* dlogits, int dl_ld,
+                          const float* dfeat) {
+  const mmvqa_model_desc& d = e->d;
+  const int H = d.hidden;
+  const long M = (long)e->B * e->T;
+  const long HM = d.head_kind == 1 ? e->B : M;
+  const float* hin = d.head_kind == 1 ? WS(e->hd_pool) : h;
+  {  // classifier[2]: logits = c1 W^T + b
+    GemmParams g = gp_linear_geom();
+    g.M = d.n_classes; g.N = H; g.K = (int)HM;
+    g.A = dlogits; g.a_ld = dl_ld;
+    g.B = WS(e->hd_c1); g.b_ld = H; g.g_Cs = H;
+    g.C = GRD(e->cls2.w); g.c_ld = H; g.c_atomic = 1;
+    RUN(PROF_IGEMM, 2.0 * HM * d.n_classes * H, mmvqa_launch_igemm(g, KIND_WGRAD, 0, 0, st));
+    RUN(PROF_OTHER, 0, k_colsum(st, dlogits, dl_ld, (int)HM, d.n_classes, GRD(e->cls2.b)));
+  }
+  TRY(lin_dgrad(e, st, dlogits, dl_ld, HM, e->cls2, WS(e->t_b), H, 0, nullptr, 0, nullptr, nullptr, 0));  // dc1
+  TRY(ln_bwd(e, st, WS(e->t_b), WS(e->hd_c0), e->cls_ln, WS(e->hd_mean), WS(e->hd_rstd), nullptr, WS(e->t_c), HM));
+  TRY(lin_wgrad(e, st, WS(e->t_c), H, WS(e->hd_u), H, HM, e->cls0, true));
+  TRY(lin_dgrad(e, st, WS(e->t_c), H, HM, e->cls0, WS(e->t_b), H, ACT_SERF, WS(e->hd_upre), H, GRD(e->fc1.b), nullptr, 0));
+  TRY(lin_wgrad(e, st, WS(e->t_b), H, hin, H, HM, e->fc1, false));
+  float* dh = WS(e->t_a);
+  if (d.head_kind == 1) {
+    TRY(lin_dgrad(e, st, WS(e->t_b), H, HM, e->fc1, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0));
+    RUN(PROF_OTHER, 0, k_meanpool_bwd(st, WS(e->t_c), e->mask, dh, e->B, e->T, H, 0));
+  } else {
+    TRY(lin_dgrad(e, st, WS(e->t_b), H, HM, e->fc1, dh, H, 0, nullptr, 0, nullptr, nullptr, 0));
+  }
+  if (d.supcon && dfeat) {
+    float* df = WS(e->t_b);  // [B][feat_dim]
+    RUN(PROF_OTHER, 0, k_l2norm_bwd(st, dfeat, e->feat, WS(e->sc_nrm), df, e->B, d.feat_dim));
+    TRY(lin_wgrad(e, st, df, d.feat_dim, WS(e->sc_a), H, e->B, e->head2, true));
+    TRY(lin_dgrad(e, st, df, d.feat_dim, e->B, e->head2, WS(e->t_c), H, ACT_SERF, WS(e->sc_pre), H, GRD(e->head0.b), nullptr, 0));
+    TRY(lin_wgrad(e, st, WS(e->t_c), H, WS(e->sc_pool), H, e->B, e->head0, false));
+    TRY(lin_dgrad(e, st, WS(e->t_c), H, e->B, e->head0, WS(e->t_d), H, 0, nullptr, 0, nullptr, nullptr, 0));
+    RUN(PROF_OTHER, 0, k_meanpool_bwd(st, WS(e->t_d), e->mask, dh, e->B, e->T, H, 1));
+  }
+  return MMVQA_OK;
+}
+
+// --------------------------------------------------------------------------- whole model
+int engine_forward(mmvqa_engine* e, hipStream_t st, const float* img, const long long* ids, const long long* seg,
+                   const long long* mask, float* logits, int logits_ld, float* feat, int training, uint32_t seed) {
+  if (!e->planned || !e->bound) return mmvqa_set_error(MMVQA_ERR_STATE, "engine_forward: plan/bind first");
+  const mmvqa_model_desc& d = e->d;
+  if (logits_ld < d.n_classes || (logits_ld & 3))
+    return mmvqa_set_error(MMVQA_ERR_ARG, "engine_forward: logits_ld=%d must be >= n_classes and %%4==0", logits_ld);
+  e->img = img; e->ids = ids; e->seg = seg; e->mask = mask;
+  e->logits = logits; e->logits_ld = logits_ld; e->feat = feat;
+  e->training = training; e->seed = seed;
+  TRY(resnet_forward(e, st));
+  const float pe = training ? d.p_emb_drop : 0.f;
+  RUN(PROF_OTHER, 0,
+      k_embed_fwd(st, ids, seg, PRM(e->emb_word), PRM(e->emb_pos), PRM(e->emb_type), PRM(e->emb_ln.g),
+                  PRM(e->emb_ln.b), WS(e->vis), WS(e->emb_out), WS(e->emb_xhat), WS(e->emb_rstd), e->B, e->T,
+                  d.hidden, d.num_vis, 1e-12f, pe, site_seed(e, 100, 0)));
+  const float* h = nullptr;
+  if (d.encoder == 0) TRY(bert_forward(e, st, WS(e->emb_out), &h));
+  else TRY(rf_forward(e, st, WS(e->emb_out), &h));
+  e->enc_out_final = (size_t)(h - e->ws);
+  return heads_forward(e, st, h);
+}
+
+int engine_backward(mmvqa_engine* e, hipStream_t st, const float* dlogits, int dl_ld, const float* dfeat) {
+  if (!e->planned || !e->bound || !e->img) return mmvqa_set_error(MMVQA_ERR_STATE, "engine_backward: run forward first");
+  const mmvqa_model_desc& d = e->d;
+  const float* h = WS(e->enc_out_final);
+  TRY(heads_backward(e, st, h, dlogits, dl_ld, dfeat));
+  if (d.encoder == 0) TRY(bert_backward(e, st, WS(e->emb_out)));
+  else TRY(rf_backward(e, st, WS(e->emb_out)));
+  const float pe = e->training ? d.p_emb_drop : 0.f;
+  RUN(PROF_OTHER, 0,
+      k_embed_bwd(st, WS(e->t_a), e->ids, e->seg, WS(e->emb_xhat), WS(e->emb_rstd), PRM(e->emb_ln.g),
+                  GRD(e->emb_word), GRD(e->emb_pos), GRD(e->emb_type), GRD(e->emb_ln.g), GRD(e->emb_ln.b),
+                  WS(e->dvis), e->B, e->T, d.hidden, d.num_vis, pe, site_seed(e, 100, 0), 0));
+  return resnet_backward(e, st);
+}
+
+int engine_create(const mmvqa_model_desc* desc, mmvqa_engine** out) {
+  if (!desc || !out) return mmvqa_set_error(MMVQA_ERR_ARG, "engine_create: null argument");
+  const mmvqa_model_desc& d = *desc;
+  if (d.hidden % 8 != 0 || d.hidden > 1024 || d.n_layers < 1 || d.num_vis != 5)
+    return mmvqa_set_error(MMVQA_ERR_ARG, "engine_create: hidden=%d n_layers=%d num_vis=%d unsupported", d.hidden,
+                           d.n_layers, d.num_vis);
+  if (d.encoder == 0 && (d.heads < 1 || d.hidden % d.heads != 0))
+    return mmvqa_set_error(MMVQA_ERR_ARG, "engine_create: heads=%d does not divide hidden=%d", d.heads, d.hidden);
+  if (d.resnet_width % 8 != 0)
+    return mmvqa_set_error(MMVQA_ERR_ARG, "engine_create: resnet_width=%d must be a multiple of 8", d.resnet_width);
+  mmvqa_engine* e = new mmvqa_engine();
+  e->d = d;
+  memset(e->prof_launch, 0, sizeof(e->prof_launch));
+  memset(e->prof_ms, 0, sizeof(e->prof_ms));
+  memset(e->prof_flops, 0, sizeof(e->prof_flops));
+  int r = build_tables(e);
+  if (r != MMVQA_OK) { delete e; return r; }
+  *out = e;
+  return MMVQA_OK;
+}
+
+int engine_profile_collect(mmvqa_engine* e) {
+  for (auto& r : e->prof) {
+    HIP_CHECK_RET(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    HIP_CHECK_RET(hipEventElapsedTime(&ms, r.a, r.b));
+    e->prof_launch[r.cls] += 1;
+    e->prof_ms[r.cls] += ms;
+    e->prof_flops[r.cls] += r.flops;
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  e->prof.clear();
+  return MMVQA_OK;
+}

@@ -1,0 +1,118 @@
+// Host runtime of the MMBERT hot path: parameter table, workspace plan and the launch sequences of
+// Model.forward / backward (models/mmbert.py:129-167).  Pure C++ over the HIP launchers in kernels.h.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+struct TensorSpec {
+  std::string name;
+  int kind;  // 0 param, 1 float buffer, 2 int64 buffer
+  int ndim;
+  long long shape[4];
+  long long offset;
+  int channels_last;
+};
+
+struct BNRef {
+  int C = 0, reps = 1;
+  long long gamma = 0, beta = 0, rmean = 0, rvar = 0, nbt = 0;
+  // plan (offsets into workspace, floats; stats in doubles from ws_d)
+  size_t stat_f = 0, stat_b = 0;  // double offsets
+  size_t scale = 0, shift = 0, mean = 0, invstd = 0, P = 0, Q = 0, R = 0;
+  double count = 0;
+};
+
+struct ConvRef {
+  long long w = 0;
+  int Cin = 0, Cout = 0, KH = 1, stride = 1, pad = 0;
+};
+
+struct BlockRef {  // torchvision Bottleneck
+  ConvRef c1, c2, c3, cd;
+  BNRef b1, b2, b3, bd;
+  bool has_ds = false;
+  int N = 0, H = 0, W = 0, OH = 0, OW = 0;   // input / output spatial dims
+  size_t z1 = 0, z2 = 0, z3 = 0, zd = 0, out = 0;  // workspace offsets
+};
+
+struct TapRef {
+  long long w = 0;
+  int C = 0;
+  int HW = 0;
+  long M = 0;
+};
+
+struct LinRef {
+  long long w = 0, b = -1;
+  int in = 0, out = 0;
+};
+
+struct LNRef {
+  long long g = 0, b = 0;
+};
+
+struct BertLayerRef {
+  LinRef qkv, proj, fc1, fc2;
+  // workspace
+  size_t xn1, mean1, rstd1, qkvo, probs, ctx, y, xn2, mean2, rstd2, pre1, h1, z;
+};
+
+struct RFLayerRef {
+  LinRef kqv, proj, ff0, ff2;
+  LNRef ln1, ln2;
+  size_t kqvo, probs, prev, res, s1, x1, mean1, rstd1, pre, hact, s2, x2, mean2, rstd2;
+};
+
+enum { PROF_IGEMM = 0, PROF_ATTN = 1, PROF_OTHER = 2, PROF_NCLS = 3 };
+
+struct mmvqa_engine {
+  mmvqa_model_desc d;
+  std::vector<TensorSpec> specs;
+  long long n_params = 0, n_bufs = 0, n_nbt = 0;
+
+  // ---- parameters
+  ConvRef stem_conv;
+  BNRef stem_bn;
+  std::vector<BlockRef> blocks;
+  int layer_end[4];          // index of last block of layer1..4
+  TapRef taps[5];            // order of the reference's return tuple: conv2(l4),conv3(l3),conv4(l2),conv5(l1),conv7(stem)
+  long long emb_word = 0, emb_pos = 0, emb_type = 0;
+  LNRef emb_ln;
+  LNRef norm1, norm2;        // BertLayer (norm2 never used: quirk 2)
+  std::vector<BertLayerRef> bert;
+  std::vector<RFLayerRef> rf;
+  LinRef fc1, cls0, cls2, head0, head2;
+  LNRef cls_ln;
+
+  // ---- plan
+  int B = 0, T = 0, IH = 0, IW = 0;
+  bool planned = false, bound = false;
+  size_t ws_floats = 0;
+  int SH = 0, SW = 0, PH = 0, PW = 0;  // stem output dims / pooled dims
+  size_t z0 = 0, p0 = 0, pool_idx = 0, vis = 0, dvis = 0, du = 0, tapgrad[5], gbuf[3], g1buf = 0, g2buf = 0,
+         dstmp = 0, statzone = 0, statzone_floats = 0;
+  size_t emb_out = 0, emb_xhat = 0, emb_rstd = 0;
+  size_t enc_out_final = 0;
+  size_t hd_upre = 0, hd_u = 0, hd_c0 = 0, hd_c1 = 0, hd_mean = 0, hd_rstd = 0, hd_pool = 0;
+  size_t sc_pool = 0, sc_pre = 0, sc_a = 0, sc_f = 0, sc_nrm = 0;
+  size_t t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_big = 0, t_dprev[2];  // backward scratch
+  // ---- bound pointers
+  float *params = nullptr, *grads = nullptr, *bufs = nullptr, *ws = nullptr;
+  long long* nbt = nullptr;
+  // ---- step state
+  const long long *ids = nullptr, *seg = nullptr, *mask = nullptr;
+  const float* img = nullptr;
+  int training = 0;
+  uint32_t seed = 0;
+  float* logits = nullptr;
+  int logits_ld = 0;
+  float* feat = nullptr;
+  // ---- profiling
+  int prof_on = 0;
+  struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+  std::vector<ProfRec> prof;
+  long long prof_launch[PROF_NCLS];
+  double prof_ms[PROF_NCLS], prof_flops[PROF_NCLS];
+};

@@ -1,0 +1,48 @@
+// Host-side launchers of the HIP kernels (defined in igemm.hip / attention.hip / elementwise.hip).
+#pragma once
+#include "common.h"
+
+int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t stream);
+int mmvqa_launch_attention(const AttnParams& p, int head_dim, int bwd, hipStream_t st);
+
+int k_bn_coef_fwd(hipStream_t st, const double* stat, int C, double count, float eps, const float* gamma,
+                  const float* beta, float* run_mean, float* run_var, long long* nbt, float momentum, int reps,
+                  int training, float* scale, float* shift, float* mean, float* invstd);
+int k_bn_coef_bwd(hipStream_t st, const double* stat, int C, double count, const float* gamma, const float* mean,
+                  const float* invstd, int training, float* P, float* Q, float* R, float* dgamma, float* dbeta);
+int k_bn_add_relu(hipStream_t st, const float* z, const float* s, const float* b, const float* idn,
+                  const float* ids, const float* idb, float* out, long rows, int C);
+int k_maxpool_fwd(hipStream_t st, const float* z, const float* s, const float* b, float* out, unsigned char* idx,
+                  int N, int H, int W, int C, int OH, int OW);
+int k_maxpool_bwd(hipStream_t st, const float* gp, const unsigned char* idx, const float* extra, const float* z,
+                  const float* s, const float* b, const float* mean, const float* invstd, float* g0, double* stat,
+                  int N, int H, int W, int C, int OH, int OW);
+int k_layernorm_fwd(hipStream_t st, const float* x, const float* res, const float* gamma, const float* beta,
+                    float* y, float* sum_out, float* mean, float* rstd, int rows, int H, float eps);
+int k_layernorm_bwd(hipStream_t st, const float* dy, const float* x, const float* gamma, const float* mean,
+                    const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta, int rows, int H);
+int k_embed_fwd(hipStream_t st, const long long* ids, const long long* seg, const float* word, const float* pos,
+                const float* type, const float* gamma, const float* beta, const float* vis, float* out,
+                float* xhat, float* rstd, int B, int T, int H, int num_vis, float eps, float drop_p, uint32_t seed);
+int k_embed_bwd(hipStream_t st, const float* dout, const long long* ids, const long long* seg, const float* xhat,
+                const float* rstd, const float* gamma, float* dword, float* dpos, float* dtype, float* dgamma,
+                float* dbeta, float* dvis, int B, int T, int H, int num_vis, float drop_p, uint32_t seed,
+                int pad_idx);
+int k_meanpool_fwd(hipStream_t st, const float* h, const long long* mask, float* out, int B, int T, int H);
+int k_meanpool_bwd(hipStream_t st, const float* dout, const long long* mask, float* dh, int B, int T, int H,
+                   int accumulate);
+int k_lsm_nll(hipStream_t st, const float* logits, int ld, const long long* target, float* row_loss,
+              long long* pred, float* dlogits, int dld, const float* gscale_ptr, float gscale_mul, int rows, int V,
+              float* out3);
+int k_asl(hipStream_t st, const float* logits, int ld, const long long* target, float* row_loss, float* dlogits,
+          int dld, int rows, int C, float gpos, float gneg, float eps, float gscale);
+int k_l2norm_fwd(hipStream_t st, const float* x, float* y, float* nrm, int rows, int D);
+int k_l2norm_bwd(hipStream_t st, const float* dy, const float* y, const float* nrm, float* dx, int rows, int D);
+int k_supcon(hipStream_t st, const float* f, float* loss, float* df, int N, int D, float temp, float base_temp,
+             float gscale);
+int k_adam(hipStream_t st, float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+           int step, float gscale, int zero_grad);
+int k_axpy(hipStream_t st, float* y, const float* x, float a, long n);
+int k_colsum(hipStream_t st, const float* x, int ld, int rows, int cols, float* out);
+int k_dropout(hipStream_t st, float* x, long n, float p, uint32_t seed);
+int k_dropout_copy(hipStream_t st, const float* x, float* y, long n, float p, uint32_t seed);

@@ -312,7 +312,7 @@ class _Abstract(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.bert_embedding = OracleBertEmbeddings(
-            vocab_size=getattr(args, "vocab_size", 30522), hidden_size=args.hidden_size,
+            vocab_size=getattr(args, "emb_vocab", getattr(args, "vocab_size", 30522)), hidden_size=args.hidden_size,
             max_position_embeddings=getattr(args, "bert_max_pos", 512))
         if "resnet" in args.cnn_encoder:
             self.trans = OracleResNetTransfer(args.hidden_size, getattr(args, "use_relu", False),

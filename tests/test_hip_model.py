@@ -1,0 +1,275 @@
+"""GPU parity of the whole hot path: mmvqa_amd.Model (HIP engine behind the reference's
+Model(args) protocol) against the CPU oracle on identical weights/inputs, plus direct replay of
+the golden vectors the REFERENCE produced.  Tolerance: 1e-3 relative to each tensor's max
+(BASELINE.json north_star: "within 1e-3 fp32"); index outputs bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import mmvqa_amd  # noqa: E402
+from mmvqa_amd import synth  # noqa: E402
+from oracle import mmbert_oracle as O  # noqa: E402
+from hip_helpers import dev, relerr  # noqa: E402
+
+TOL = 1e-3
+
+
+def zero_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+
+
+def mini_args(**kw):
+    d = dict(resnet_layers=(1, 1, 1, 1), resnet_width=8, hidden_size=96, n_layers=2, heads=12, vocab_size=50,
+             emb_vocab=50, bert_max_pos=32, hidden_dropout_prob=0.0, emb_dropout_prob=0.0, rf_dropout_prob=0.0)
+    d.update(kw)
+    return O.make_args(**d)
+
+
+def build_pair(args, seed=0):
+    torch.manual_seed(seed)
+    oargs = O.make_args(**{**vars(args), "vocab_size": args.vocab_size})
+    orc = O.OracleModel(oargs)
+    # randomise BN affine / running stats so that mistakes there are visible
+    with torch.no_grad():
+        for m in orc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    zero_dropout(orc)
+    hip = mmvqa_amd.Model(args)
+    hip.load_state_dict(orc.state_dict())
+    hip.to(dev())
+    return orc, hip
+
+
+def compare_grads(orc, hip, tol=TOL):
+    bad = []
+    hp = dict(hip.named_parameters())
+    for name, p in orc.named_parameters():
+        g_ref = p.grad
+        g = hp[name].grad
+        if g_ref is None:
+            assert g is None or float(g.abs().max()) == 0.0, f"{name}: reference has no gradient"
+            continue
+        assert g is not None, f"{name}: missing gradient"
+        e = relerr(g, g_ref)
+        if not e <= tol:
+            bad.append((name, e))
+    assert not bad, "gradient mismatches: " + ", ".join(f"{n} {e:.2e}" for n, e in bad[:12])
+
+
+def run_case(args, B, T, hw, kind, seed=0):
+    orc, hip = build_pair(args, seed)
+    V = args.vocab_size
+    if kind == "vqa":
+        img, ids, seg, mask, tgt = synth.vqa_batch(B, T, hw, vocab=args.emb_vocab, n_classes=V, seed=5)
+    else:
+        img, ids, seg, mask, tgt = synth.roco_batch(B, T, hw, vocab=V, seed=5, mlm_prob=0.3)
+    orc.train()
+    hip.train()
+    out_ref = orc(img, ids, seg, mask)
+    out = hip(img.to(dev()), ids.to(dev()), seg.to(dev()), mask.to(dev()))
+    if kind == "vqa":
+        assert out[1] == 0 and out[2] == 0
+        logits, logits_ref = out[0], out_ref[0]
+        loss_ref = O.asl_single_label(logits_ref, tgt)
+        loss = mmvqa_amd.asl_loss(logits, tgt.to(dev()))
+    elif kind == "supcon":
+        logits, feat = out
+        logits_ref, feat_ref = out_ref
+        assert relerr(feat, feat_ref) <= TOL, f"feat {relerr(feat, feat_ref):.2e}"
+        loss_ref = O.mlm_loss(logits_ref, tgt)[0] + O.supcon_simclr(O.split_feat(feat_ref, B // 2))
+        loss = mmvqa_amd.mlm_loss(logits, tgt.to(dev()))[0] + mmvqa_amd.supcon_loss(mmvqa_amd.split_feat(feat, B // 2))
+    else:
+        logits, logits_ref = out, out_ref
+        loss_ref = O.mlm_loss(logits_ref, tgt)[0]
+        loss = mmvqa_amd.mlm_loss(logits, tgt.to(dev()))[0]
+    e = relerr(logits, logits_ref)
+    assert e <= TOL, f"logits rel err {e:.2e}"
+    assert abs(float(loss) - float(loss_ref)) <= TOL * abs(float(loss_ref)), (float(loss), float(loss_ref))
+    loss_ref.backward()
+    loss.backward()
+    compare_grads(orc, hip)
+    # BatchNorm running statistics incl. the k-fold update rule (quirk 7)
+    hsd, osd = hip.state_dict(), orc.state_dict()
+    for k, v in osd.items():
+        if "running_" in k:
+            assert relerr(hsd[k], v) <= 1e-4, f"{k}: {relerr(hsd[k], v):.2e}"
+        if k.endswith("num_batches_tracked"):
+            assert int(hsd[k]) == int(v), k
+    return orc, hip
+
+
+@pytest.mark.parametrize("tm", ["transformer", "realformer"])
+def test_mlm_mini(tm):
+    run_case(mini_args(transformer_model=tm), B=3, T=12, hw=32, kind="mlm")
+
+
+def test_mlm_supcon_mini():
+    run_case(mini_args(transformer_model="realformer", supcon=True), B=4, T=11, hw=32, kind="supcon")
+
+
+@pytest.mark.parametrize("tm", ["transformer", "realformer"])
+def test_vqa_mini(tm):
+    run_case(mini_args(transformer_model=tm, dataset="VQA-Med", vocab_size=23), B=3, T=10, hw=32, kind="vqa")
+
+
+def test_deeper_backbone_relu_taps():
+    """identity blocks, several blocks per layer, --use_relu taps, T=32, odd image size"""
+    run_case(mini_args(resnet_layers=(2, 2, 3, 2), resnet_width=16, use_relu=True), B=2, T=32, hw=72, kind="mlm")
+
+
+def test_full_width_hidden768():
+    """real channel widths (64..2048) and hidden 768 with a one-block-per-layer backbone"""
+    run_case(mini_args(resnet_width=64, hidden_size=768, n_layers=1, vocab_size=300, emb_vocab=300), B=2, T=32,
+             hw=64, kind="mlm")
+
+
+@pytest.mark.parametrize("tag,tm,ds,supcon", [
+    ("model_tr_roco", "transformer", "roco", False),
+    ("model_rf_roco_supcon", "realformer", "roco", True),
+    ("model_tr_vqa", "transformer", "VQA-Med", False),
+    ("model_rf_vqa", "realformer", "VQA-Med", False),
+])
+def test_golden_reference_replay(golden_dir, tag, tm, ds, supcon):
+    """inputs/outputs recorded from the REFERENCE's own Model.forward (tests/golden/make_golden.py)"""
+    g = dict(np.load(os.path.join(golden_dir, tag + ".npz"), allow_pickle=False))
+    B, T, hw, V = [int(v) for v in g["dims"]]
+    kw = dict(transformer_model=tm, dataset=ds, hidden_size=768, n_layers=2, heads=12, hidden_dropout_prob=0.0,
+              emb_dropout_prob=0.0, rf_dropout_prob=0.0, vocab_size=V, emb_vocab=V, resnet_layers=(1, 1, 1, 1),
+              resnet_width=64, bert_max_pos=32)
+    if supcon:
+        kw["supcon"] = True
+    args = O.make_args(**kw)
+    torch.manual_seed(int(g["seed"]))
+    orc = O.OracleModel(args)   # same seeded weights the reference ran with
+    hip = mmvqa_amd.Model(args)
+    hip.load_state_dict(orc.state_dict())
+    hip.to(dev()).train()
+    t = lambda k: torch.from_numpy(g[k]).to(dev())  # noqa: E731
+    out = hip(t("img"), t("ids"), t("seg"), t("mask"))
+    tgt = t("target")
+    if ds == "roco":
+        logits = out[0] if supcon else out
+        loss = mmvqa_amd.mlm_loss(logits, tgt)[0]
+        if supcon:
+            assert relerr(out[1], torch.from_numpy(g["feat"])) <= TOL
+            loss = loss + mmvqa_amd.supcon_loss(mmvqa_amd.split_feat(out[1], B // 2))
+    else:
+        logits = out[0]
+        loss = mmvqa_amd.asl_loss(logits, tgt)
+    e = relerr(logits, torch.from_numpy(g["logits"]))
+    assert e <= TOL, f"logits vs reference {e:.2e}"
+    assert abs(float(loss) - float(g["loss"])) <= TOL * abs(float(g["loss"]))
+    loss.backward()
+    hp = dict(hip.named_parameters())
+    for k in g:
+        if not k.startswith("g_"):
+            continue
+        name = k[2:].replace("__", ".")
+        gr = hp[name].grad
+        if gr.numel() > 8192:
+            gr = gr.flatten()[:: max(1, gr.numel() // 4096)][:4096]
+        e = relerr(gr, torch.from_numpy(g[k]))
+        assert e <= 2 * TOL, f"{name}: {e:.2e}"
+    hsd = hip.state_dict()
+    for k in g:
+        if k.startswith("b_"):
+            assert relerr(hsd[k[2:].replace("__", ".")].double(), torch.from_numpy(g[k]).double()) <= 1e-4, k
+
+
+def test_eval_mode_and_state_dict_roundtrip():
+    args = mini_args()
+    orc, hip = build_pair(args, seed=3)
+    img, ids, seg, mask, tgt = synth.roco_batch(3, 12, 32, vocab=50, seed=9)
+    orc.eval()
+    hip.eval()
+    with torch.no_grad():
+        ref = orc(img, ids, seg, mask)
+        out = hip(img.to(dev()), ids.to(dev()), seg.to(dev()), mask.to(dev()))
+    assert relerr(out, ref) <= TOL
+    sd = {k: v.cpu() for k, v in hip.state_dict().items()}
+    hip2 = mmvqa_amd.Model(args)
+    hip2.load_state_dict(sd)
+    hip2.to(dev()).eval()
+    with torch.no_grad():
+        out2 = hip2(img.to(dev()), ids.to(dev()), seg.to(dev()), mask.to(dev()))
+    assert torch.equal(out2, out)
+
+
+def test_rehead_surgery_and_fused_adam():
+    """vqamed2019/train.py:125-149 (classifier[2] swap) then one optimizer step vs torch.optim.Adam"""
+    args = mini_args(dataset="VQA-Med", vocab_size=50)
+    orc, hip = build_pair(args, seed=4)
+    torch.manual_seed(7)
+    new_head = torch.nn.Linear(96, 17)
+    orc.classifier[2] = torch.nn.Linear(96, 17)
+    orc.classifier[2].load_state_dict(new_head.state_dict())
+    hip.classifier[2] = new_head
+    assert hip.state_dict()["classifier.2.weight"].shape == (17, 96)
+    assert str(hip.flat_params.device).startswith("cuda")
+    img, ids, seg, mask, tgt = synth.vqa_batch(3, 10, 32, vocab=50, n_classes=17, seed=2)
+    opt_ref = torch.optim.Adam(orc.parameters(), lr=1e-3)
+    opt = mmvqa_amd.FusedAdam(hip, lr=1e-3)
+    orc.train()
+    hip.train()
+    for _ in range(2):
+        opt_ref.zero_grad()
+        l_ref = O.asl_single_label(orc(img, ids, seg, mask)[0], tgt)
+        l_ref.backward()
+        opt_ref.step()
+        l = mmvqa_amd.asl_loss(hip(img.to(dev()), ids.to(dev()), seg.to(dev()), mask.to(dev()))[0], tgt.to(dev()))
+        l.backward()
+        opt.step()
+    hsd = hip.state_dict()
+    worst = max(relerr(hsd[k], v) for k, v in orc.state_dict().items() if v.dtype.is_floating_point)
+    assert worst <= 2e-3, worst
+
+
+def test_dropout_training_mode():
+    args = mini_args(hidden_dropout_prob=0.3, emb_dropout_prob=0.1)
+    _, hip = build_pair(args, seed=5)
+    img, ids, seg, mask, tgt = (t.to(dev()) for t in synth.roco_batch(4, 16, 32, vocab=50, seed=3))
+    hip.train()
+    hip.set_seed(11)
+    a = hip(img, ids, seg, mask)
+    la = mmvqa_amd.mlm_loss(a, tgt)[0]
+    la.backward()
+    ga = hip.flat_grads.clone()
+    hip.set_seed(11)
+    hip.flat_grads.zero_()
+    b = hip(img, ids, seg, mask)
+    mmvqa_amd.mlm_loss(b, tgt)[0].backward()
+    hip.set_seed(12)
+    c = hip(img, ids, seg, mask)
+    assert torch.isfinite(a).all() and torch.isfinite(ga).all()
+    assert relerr(b, a) < 1e-5                                   # same seed -> same masks
+    assert relerr(hip.flat_grads, ga) < 1e-3                     # (atomics reorder sums slightly)
+    assert relerr(c, a) > 1e-3                                   # different seed -> different masks
+    # finite-difference check of the training-mode gradient along a random direction (same mask)
+    hip.set_seed(11)
+    d = torch.randn_like(hip.flat_params) * (hip.flat_params.abs() > 0)
+    d = d / d.norm()
+    eps = 1e-2
+    with torch.no_grad():
+        hip.flat_params.add_(d, alpha=eps)
+        hip.set_seed(11)
+        lp = float(mmvqa_amd.mlm_loss(hip(img, ids, seg, mask), tgt)[0])
+        hip.flat_params.add_(d, alpha=-2 * eps)
+        hip.set_seed(11)
+        lm = float(mmvqa_amd.mlm_loss(hip(img, ids, seg, mask), tgt)[0])
+        hip.flat_params.add_(d, alpha=eps)
+    fd = (lp - lm) / (2 * eps)
+    an = float((ga * d).sum())
+    assert abs(fd - an) <= 0.1 * max(abs(an), 1e-3), (fd, an)

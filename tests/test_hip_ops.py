@@ -1,0 +1,546 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI, against torch CPU
+fp32 arithmetic of the same op (tolerance 1e-4 relative to the tensor's max, far inside the
+1e-3 end-to-end budget; index outputs bit-exact)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hip_helpers import *  # noqa: E402,F401,F403
+from oracle import mmbert_oracle as O  # noqa: E402
+
+TOL = 1e-4
+
+
+def ACT(name):
+    return dict(none=L.ACT_NONE, relu=L.ACT_RELU, gelu=L.ACT_GELU, serf=L.ACT_SERF)[name]
+
+
+def act_cpu(name, x):
+    return dict(none=lambda t: t, relu=torch.relu, gelu=O.gelu, serf=O.serf)[name](x)
+
+
+# ----------------------------------------------------------------------------- linear (igemm FWD/DGRAD/WGRAD)
+@pytest.mark.parametrize("M,K,N,act,tile", [(70, 96, 50, "none", 0), (512, 768, 2304, "gelu", 0),
+                                           (130, 64, 130, "serf", 1), (33, 100, 257, "relu", 2),
+                                           (200, 40, 64, "none", 3), (64, 256, 300, "none", 4)])
+def test_linear_fwd(M, K, N, act, tile):
+    torch.manual_seed(0)
+    x, w, b, r = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K), torch.randn(N), torch.randn(M, N)
+    xd, wd, bd, rd = (t.to(dev()) for t in (x, w, b, r))
+    ldy = (N + 3) & ~3
+    y = torch.zeros(M, ldy, device=dev())
+    pre = torch.zeros(M, ldy, device=dev())
+    d = L.GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.a_ld, d.g_Cs = P(xd), K, K
+    d.B, d.b_ld = P(wd), K
+    linear_geom(d)
+    d.C, d.c_ld, d.Cpre, d.bias, d.act = P(y), ldy, P(pre), P(bd), ACT(act)
+    d.R, d.r_ld = P(rd), N
+    run_igemm(d, L.KIND_FWD, 0, tile)
+    ref_pre = x @ w.T + b
+    assert_close(pre[:, :N], ref_pre, TOL, "pre")
+    assert_close(y[:, :N], act_cpu(act, ref_pre) + r, TOL, "y")
+
+
+def test_linear_bwd():
+    torch.manual_seed(1)
+    M, K, N = 96, 72, 130   # N not a multiple of 4: padded leading dimension (the vocab case)
+    x = torch.randn(M, K, requires_grad=True)
+    w = (torch.randn(N, K) / math.sqrt(K)).requires_grad_(True)
+    pre = x @ w.T
+    gy = torch.randn(M, N)
+    O.serf(pre).backward(gy)
+    p2 = pre.detach().clone().requires_grad_(True)
+    O.serf(p2).backward(gy)
+    gpre = p2.grad                      # gradient wrt pre = gy * serf'(pre)
+    ld = (N + 3) & ~3
+    gp = torch.full((M, ld), float("nan"))   # pad columns hold garbage on purpose
+    gp[:, :N] = gpre
+    gpd, xd, wd = gp.to(dev()), x.detach().to(dev()), w.detach().to(dev())
+    dx = torch.zeros(M, K, device=dev())
+    d = L.GemmDesc()
+    d.M, d.N, d.K = M, K, N
+    d.A, d.a_ld, d.g_Cs = P(gpd), ld, N
+    d.B, d.b_ld = P(wd), K
+    linear_geom(d)
+    d.C, d.c_ld = P(dx), K
+    run_igemm(d, L.KIND_DGRAD)
+    assert_close(dx, x.grad, TOL, "dx")
+    dw = torch.zeros(N, K, device=dev())
+    d = L.GemmDesc()
+    d.M, d.N, d.K = N, K, M
+    d.A, d.a_ld = P(gpd), ld
+    d.B, d.b_ld, d.g_Cs = P(xd), K, K
+    linear_geom(d)
+    d.C, d.c_ld, d.c_atomic = P(dw), K, 1
+    run_igemm(d, L.KIND_WGRAD)
+    assert_close(dw, w.grad, TOL, "dw")
+
+
+def test_dgrad_fused_act_backward():
+    """fc2-dgrad epilogue: dpre = (dy W2) * act'(pre), with the bias-gradient column sums"""
+    torch.manual_seed(14)
+    M, Hh, F4 = 64, 48, 132
+    dy, w2, pre = torch.randn(M, Hh), torch.randn(Hh, F4) / 7, torch.randn(M, F4) * 2
+    for act in ("gelu", "serf"):
+        pr = pre.clone().requires_grad_(True)
+        (act_cpu(act, pr) @ w2.T).backward(dy)
+        out = torch.zeros(M, F4, device=dev())
+        cs = torch.zeros(F4, device=dev())
+        dyd, w2d, pred = dy.to(dev()), w2.to(dev()), pre.to(dev())
+        d = L.GemmDesc()
+        d.M, d.N, d.K = M, F4, Hh
+        d.A, d.a_ld, d.g_Cs = P(dyd), Hh, Hh
+        d.B, d.b_ld = P(w2d), F4
+        linear_geom(d)
+        d.C, d.c_ld = P(out), F4
+        d.dact, d.Pre, d.pre_ld, d.colsum = ACT(act), P(pred), F4, P(cs)
+        run_igemm(d, L.KIND_DGRAD)
+        assert_close(out, pr.grad, TOL, "dact " + act)
+        assert_close(cs, pr.grad.sum(0), TOL, "colsum " + act)
+
+
+# ----------------------------------------------------------------------------- convolution
+CONVS = [  # N, H, W, Cin, Cout, K, stride, pad
+    (2, 9, 9, 8, 16, 3, 1, 1), (2, 9, 9, 8, 16, 3, 2, 1), (3, 8, 8, 16, 24, 1, 1, 0), (2, 9, 9, 16, 8, 1, 2, 0),
+    (2, 14, 14, 64, 64, 3, 1, 1), (1, 7, 7, 40, 72, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_fwd_bwd(cfg):
+    N, H, W, Cin, Cout, K, s, p = cfg
+    torch.manual_seed(2)
+    x_raw = torch.randn(N, Cin, H, W)
+    sc, sh = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.3
+    w = torch.randn(Cout, Cin, K, K) / math.sqrt(Cin * K * K)
+    # forward: z = conv(relu(x*sc+sh)) with fused statistics
+    a = torch.relu(x_raw * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    z_ref = F.conv2d(a, wr, stride=s, padding=p)
+    OH, OW = z_ref.shape[2:]
+    xd, wd = nhwc(x_raw), w_ohwi(w)
+    scd, shd = sc.to(dev()), sh.to(dev())
+    z = torch.zeros(N * OH * OW, Cout, device=dev())
+    stat = torch.zeros(L.STAT_SLOTS, Cout, 2, dtype=torch.float64, device=dev())
+    d, _, _ = conv_desc_fwd(xd, wd, N, H, W, Cin, Cout, K, s, p, z)
+    d.a_pro, d.a_c0, d.a_c1 = L.PRO_AFFINE_RELU, P(scd), P(shd)
+    d.stat1, d.stat_bwd = P(stat), 0
+    run_igemm(d, L.KIND_FWD)
+    assert_close(from_nhwc(z, N, OH, OW, Cout), z_ref, TOL, "z")
+    st = stat.sum(0).cpu()
+    assert_close(st[:, 0], z_ref.sum(dim=(0, 2, 3)).double(), 1e-5, "sum")
+    assert_close(st[:, 1], (z_ref.double() ** 2).sum(dim=(0, 2, 3)), 1e-5, "sumsq")
+    # backward through dz = Pc*G + Qc*z + Rc (BatchNorm-backward prologue with arbitrary coefficients)
+    G = torch.randn_like(z_ref)
+    Pc, Qc, Rc = torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1
+    dz = G * Pc[None, :, None, None] + z_ref.detach() * Qc[None, :, None, None] + Rc[None, :, None, None]
+    z_ref.backward(dz)
+    Gd, zd = nhwc(G), z
+    coef = [t.to(dev()) for t in (Pc, Qc, Rc)]
+    # dgrad with ReLU mask of the producer + BN-backward statistics on x_raw
+    mu, istd = torch.randn(Cin) * 0.1, torch.rand(Cin) + 0.5
+    dx = torch.zeros(N * H * W, Cin, device=dev())
+    bst = torch.zeros(L.STAT_SLOTS, Cin, 2, dtype=torch.float64, device=dev())
+    d = conv_desc_dgrad(Gd, wd, N, H, W, Cin, Cout, K, s, p, dx)
+    d.A2, d.a_pro, d.a_c0, d.a_c1, d.a_c2 = P(zd), L.PRO_DZ, P(coef[0]), P(coef[1]), P(coef[2])
+    d.Mk, d.mk_ld, d.mk_s, d.mk_b = P(xd), Cin, P(scd), P(shd)
+    mud, isd = mu.to(dev()), istd.to(dev())
+    d.stat1, d.stat_bwd, d.Z1, d.z1_ld, d.mean1, d.invstd1 = P(bst), 1, P(xd), Cin, P(mud), P(isd)
+    run_igemm(d, L.KIND_DGRAD)
+    mask = (x_raw * sc[None, :, None, None] + sh[None, :, None, None] > 0).float()
+    g_ref = a.grad * mask
+    assert_close(from_nhwc(dx, N, H, W, Cin), g_ref, TOL, "dgrad")
+    xhat = (x_raw - mu[None, :, None, None]) * istd[None, :, None, None]
+    bs = bst.sum(0).cpu()
+    assert_close(bs[:, 0], g_ref.sum(dim=(0, 2, 3)).double(), 1e-4, "sum g")
+    assert_close(bs[:, 1], (g_ref * xhat).sum(dim=(0, 2, 3)).double(), 1e-4, "sum g xhat")
+    # wgrad with the producer's BN+ReLU applied to x on the fly
+    dw = torch.zeros(Cout, K * K * Cin, device=dev())
+    d = conv_desc_wgrad(Gd, xd, N, H, W, Cin, Cout, K, s, p, dw)
+    d.A2, d.a_pro, d.a_c0, d.a_c1, d.a_c2 = P(zd), L.PRO_DZ, P(coef[0]), P(coef[1]), P(coef[2])
+    d.b_pro, d.b_c0, d.b_c1 = L.PRO_AFFINE_RELU, P(scd), P(shd)
+    run_igemm(d, L.KIND_WGRAD)
+    assert_close(dw.view(Cout, K, K, Cin).permute(0, 3, 1, 2), wr.grad, TOL, "wgrad")
+
+
+def test_stem_conv():
+    torch.manual_seed(3)
+    N, H, W, Cout = 2, 20, 22, 16
+    img = torch.randn(N, 3, H, W)
+    w = (torch.randn(Cout, 3, 7, 7) / 12).requires_grad_(True)
+    z_ref = F.conv2d(img, w, stride=2, padding=3)
+    OH, OW = z_ref.shape[2:]
+    imgd, wd = img.to(dev()), w_ohwi(w.detach())
+    z = torch.zeros(N * OH * OW, Cout, device=dev())
+    d = L.GemmDesc()
+    d.M, d.N, d.K = N * OH * OW, Cout, 147
+    d.A, d.g_nchw = P(imgd), 1
+    d.g_SH, d.g_SW, d.g_Cs, d.g_OH, d.g_OW = H, W, 3, OH, OW
+    d.g_KH = d.g_KW = 7
+    d.g_stride, d.g_pad = 2, 3
+    d.B, d.b_ld, d.C, d.c_ld = P(wd), 147, P(z), Cout
+    run_igemm(d, L.KIND_FWD, 1)
+    assert_close(from_nhwc(z, N, OH, OW, Cout), z_ref, TOL, "stem z")
+    G = torch.randn_like(z_ref)
+    z_ref.backward(G)
+    Gd = nhwc(G)
+    one, zero = torch.ones(Cout, device=dev()), torch.zeros(Cout, device=dev())
+    dw = torch.zeros(Cout, 147, device=dev())
+    d = L.GemmDesc()
+    d.M, d.N, d.K = Cout, 147, N * OH * OW
+    d.A, d.A2, d.a_ld, d.a_pro, d.a_c0, d.a_c1, d.a_c2 = P(Gd), P(z), Cout, L.PRO_DZ, P(one), P(zero), P(zero)
+    d.B, d.g_nchw = P(imgd), 1
+    d.g_SH, d.g_SW, d.g_Cs, d.g_OH, d.g_OW = H, W, 3, OH, OW
+    d.g_KH = d.g_KW = 7
+    d.g_stride, d.g_pad = 2, 3
+    d.C, d.c_ld, d.c_atomic = P(dw), 147, 1
+    run_igemm(d, L.KIND_WGRAD, 1)
+    assert_close(dw.view(Cout, 7, 7, 3).permute(0, 3, 1, 2), w.grad, TOL, "stem dw")
+
+
+def test_tap_fwd_bwd():
+    """models/image_encoding.py:53-62: v = mean_hw(act(conv1x1(fmap)))"""
+    torch.manual_seed(4)
+    N, HW, Cc, Hd = 3, 49, 40, 96
+    f = torch.randn(N, HW, Cc, requires_grad=True)
+    w = (torch.randn(Hd, Cc) / math.sqrt(Cc)).requires_grad_(True)
+    v_ref = O.serf(f @ w.T).mean(1)
+    dv = torch.randn(N, Hd)
+    v_ref.backward(dv)
+    fd, wd, dvd = f.detach().reshape(N * HW, Cc).to(dev()), w.detach().to(dev()), dv.to(dev())
+    v = torch.zeros(N, Hd, device=dev())
+    d = L.GemmDesc()
+    d.M, d.N, d.K = N * HW, Hd, Cc
+    d.A, d.a_ld, d.g_Cs, d.B, d.b_ld = P(fd), Cc, Cc, P(wd), Cc
+    linear_geom(d)
+    d.epi_mode, d.act, d.tap_HW, d.tap_out, d.C, d.c_ld = L.EPI_TAP_FWD, L.ACT_SERF, HW, P(v), P(v), Hd
+    run_igemm(d, L.KIND_FWD)
+    assert_close(v, v_ref, TOL, "tap v")
+    du = torch.zeros(N * HW, Hd, device=dev())
+    d.epi_mode, d.tap_out, d.tap_dv, d.C = L.EPI_TAP_BWD, None, P(dvd), P(du)
+    run_igemm(d, L.KIND_FWD)
+    pre = (f.detach() @ w.detach().T).requires_grad_(True)
+    O.serf(pre).mean(1).backward(dv)
+    assert_close(du.view(N, HW, Hd), pre.grad, TOL, "tap du")
+
+
+# ----------------------------------------------------------------------------- BatchNorm pieces
+def test_bn_coef_and_add_relu():
+    torch.manual_seed(5)
+    N, Cc, H, W = 4, 16, 6, 6
+    z = torch.randn(N, Cc, H, W) * 2 + 1
+    bn = torch.nn.BatchNorm2d(Cc)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    bn.train()
+    y_ref = bn(z)
+    M = N * H * W
+    stat = torch.zeros(L.STAT_SLOTS, Cc, 2, dtype=torch.float64)
+    stat[3, :, 0] = z.double().sum(dim=(0, 2, 3))
+    stat[5, :, 1] = (z.double() ** 2).sum(dim=(0, 2, 3))
+    statd = stat.to(dev())
+    rm, rv = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())
+    nbt = torch.zeros(1, dtype=torch.int64, device=dev())
+    out = [torch.zeros(Cc, device=dev()) for _ in range(4)]
+    g, b = bn.weight.detach().to(dev()), bn.bias.detach().to(dev())
+    L.check(L.lib().mmvqa_bn_coef_fwd(L.stream_ptr(), P(statd), Cc, float(M), 1e-5, P(g), P(b), P(rm), P(rv), P(nbt),
+                                      0.1, 1, 1, *[P(t) for t in out]))
+    torch.cuda.synchronize()
+    assert_close(rm, bn.running_mean, 1e-5, "running_mean")
+    assert_close(rv, bn.running_var, 1e-5, "running_var")
+    assert int(nbt) == 1
+    zd = nhwc(z)
+    idn = torch.randn(N, Cc, H, W)
+    o = torch.zeros(M, Cc, device=dev())
+    L.check(L.lib().mmvqa_bn_add_relu(L.stream_ptr(), P(zd), P(out[0]), P(out[1]), P(nhwc(idn)), None, None, P(o), M, Cc))
+    torch.cuda.synchronize()
+    assert_close(from_nhwc(o, N, H, W, Cc), torch.relu(y_ref + idn), TOL, "bn_add_relu")
+    # k-fold update rule (quirk 7)
+    rm2, rv2 = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())
+    L.check(L.lib().mmvqa_bn_coef_fwd(L.stream_ptr(), P(statd), Cc, float(M), 1e-5, P(g), P(b), P(rm2), P(rv2), P(nbt),
+                                      0.1, 5, 1, *[P(t) for t in out]))
+    bn2 = torch.nn.BatchNorm2d(Cc).train()
+    for _ in range(5):
+        bn2(z)
+    assert_close(rm2, bn2.running_mean, 1e-5, "running_mean x5")
+    assert_close(rv2, bn2.running_var, 1e-5, "running_var x5")
+    assert int(nbt) == 6
+
+
+def test_maxpool():
+    torch.manual_seed(6)
+    N, Cc, H, W = 2, 8, 11, 12
+    z = torch.randn(N, Cc, H, W)
+    sc, sh = torch.rand(Cc) + 0.5, torch.randn(Cc) * 0.2
+    a = torch.relu(z * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    p_ref = F.max_pool2d(a, 3, 2, 1)
+    OH, OW = p_ref.shape[2:]
+    gp = torch.randn_like(p_ref)
+    p_ref.backward(gp)
+    zd, scd, shd = nhwc(z), sc.to(dev()), sh.to(dev())
+    out = torch.zeros(N * OH * OW, Cc, device=dev())
+    idx = torch.zeros(N * OH * OW * Cc, dtype=torch.uint8, device=dev())
+    L.check(L.lib().mmvqa_maxpool_fwd(L.stream_ptr(), P(zd), P(scd), P(shd), P(out), P(idx), N, H, W, Cc, OH, OW))
+    assert_close(from_nhwc(out, N, OH, OW, Cc), p_ref, 1e-6, "maxpool fwd")
+    extra = torch.randn(N, Cc, H, W)
+    mu, istd = torch.randn(Cc) * 0.1, torch.rand(Cc) + 0.5
+    g0 = torch.zeros(N * H * W, Cc, device=dev())
+    stat = torch.zeros(L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=dev())
+    L.check(L.lib().mmvqa_maxpool_bwd(L.stream_ptr(), P(nhwc(gp)), P(idx), P(nhwc(extra)), P(zd), P(scd), P(shd),
+                                      P(mu.to(dev())), P(istd.to(dev())), P(g0), P(stat), N, H, W, Cc, OH, OW))
+    torch.cuda.synchronize()
+    mask = (a.detach() > 0).float()
+    g_ref = (a.grad + extra) * mask
+    assert_close(from_nhwc(g0, N, H, W, Cc), g_ref, 1e-5, "maxpool bwd")
+    xh = (z - mu[None, :, None, None]) * istd[None, :, None, None]
+    st = stat.sum(0).cpu()
+    assert_close(st[:, 0], g_ref.sum(dim=(0, 2, 3)).double(), 1e-5, "sum g")
+    assert_close(st[:, 1], (g_ref * xh).sum(dim=(0, 2, 3)).double(), 1e-5, "sum g xhat")
+
+
+# ----------------------------------------------------------------------------- LayerNorm / embeddings
+@pytest.mark.parametrize("rows,H,eps", [(37, 96, 1e-12), (512, 768, 1e-12), (64, 768, 1e-5)])
+def test_layernorm(rows, H, eps):
+    torch.manual_seed(7)
+    x = (torch.randn(rows, H) * 2 + 0.5).requires_grad_(True)
+    r = torch.randn(rows, H).requires_grad_(True)
+    g, b = (torch.rand(H) + 0.5).requires_grad_(True), torch.randn(H).requires_grad_(True)
+    y_ref = F.layer_norm(x + r, (H,), g, b, eps)
+    dy, dres = torch.randn(rows, H), torch.randn(rows, H)
+    y_ref.backward(dy)
+    xd, rd, gd, bd = (t.detach().to(dev()) for t in (x, r, g, b))
+    y, s = torch.zeros(rows, H, device=dev()), torch.zeros(rows, H, device=dev())
+    mean, rstd = torch.zeros(rows, device=dev()), torch.zeros(rows, device=dev())
+    L.check(L.lib().mmvqa_layernorm_fwd(L.stream_ptr(), P(xd), P(rd), P(gd), P(bd), P(y), P(s), P(mean), P(rstd), rows, H, eps))
+    assert_close(y, y_ref, TOL, "ln y")
+    dx = torch.zeros(rows, H, device=dev())
+    dg, db = torch.zeros(H, device=dev()), torch.zeros(H, device=dev())
+    L.check(L.lib().mmvqa_layernorm_bwd(L.stream_ptr(), P(dy.to(dev())), P(s), P(gd), P(mean), P(rstd), P(dres.to(dev())),
+                                        P(dx), P(dg), P(db), rows, H))
+    torch.cuda.synchronize()
+    assert_close(dx, x.grad + dres, TOL, "ln dx")
+    assert_close(dg, g.grad, TOL, "ln dgamma")
+    assert_close(db, b.grad, TOL, "ln dbeta")
+
+
+def test_embed():
+    torch.manual_seed(8)
+    B, T, H, V, nv = 3, 12, 96, 40, 5
+    emb = O.OracleBertEmbeddings(V, H, 32).eval()
+    ids = torch.randint(0, V, (B, T))
+    ids[:, 1:6] = 0
+    seg = torch.randint(0, 2, (B, T))
+    vis = torch.randn(nv, B, H, requires_grad=True)
+    h = emb(ids, seg).clone()
+    for n in range(nv):
+        h[:, n, :] = vis[n]
+    dh = torch.randn(B, T, H)
+    h.backward(dh)
+    sd = {k: v.detach().to(dev()) for k, v in emb.state_dict().items()}
+    out, xh = torch.zeros(B * T, H, device=dev()), torch.zeros(B * T, H, device=dev())
+    rstd = torch.zeros(B * T, device=dev())
+    idsd, segd, visd = ids.to(dev()), seg.to(dev()), vis.detach().to(dev())
+    L.check(L.lib().mmvqa_embed_fwd(L.stream_ptr(), P(idsd), P(segd), P(sd["word_embeddings.weight"]),
+                                    P(sd["position_embeddings.weight"]), P(sd["token_type_embeddings.weight"]),
+                                    P(sd["LayerNorm.weight"]), P(sd["LayerNorm.bias"]), P(visd), P(out), P(xh), P(rstd),
+                                    B, T, H, nv, 1e-12, 0.0, 0))
+    assert_close(out.view(B, T, H), h, TOL, "embed fwd")
+    dw, dp, dt = (torch.zeros_like(sd[k]) for k in ("word_embeddings.weight", "position_embeddings.weight",
+                                                     "token_type_embeddings.weight"))
+    dg, db = torch.zeros(H, device=dev()), torch.zeros(H, device=dev())
+    dvis = torch.zeros(nv, B, H, device=dev())
+    L.check(L.lib().mmvqa_embed_bwd(L.stream_ptr(), P(dh.to(dev())), P(idsd), P(segd), P(xh), P(rstd),
+                                    P(sd["LayerNorm.weight"]), P(dw), P(dp), P(dt), P(dg), P(db), P(dvis), B, T, H, nv,
+                                    0.0, 0, 0))
+    torch.cuda.synchronize()
+    assert_close(dvis, vis.grad, 1e-6, "dvis")
+    assert_close(dw, emb.word_embeddings.weight.grad, TOL, "dword")
+    assert torch.all(dw[0] == 0)  # padding_idx row
+    assert_close(dp, emb.position_embeddings.weight.grad, TOL, "dpos")
+    assert_close(dt, emb.token_type_embeddings.weight.grad, TOL, "dtype")
+    assert_close(dg, emb.LayerNorm.weight.grad, TOL, "dgamma")
+    assert_close(db, emb.LayerNorm.bias.grad, TOL, "dbeta")
+
+
+# ----------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,T,heads,D", [(2, 32, 12, 64), (3, 10, 12, 8), (2, 28, 12, 64), (2, 40, 4, 64),
+                                         (1, 75, 2, 64)])
+def test_attention_bert(B, T, heads, D):
+    """models/transformer.py:19-30 (key-axis mask), ragged masks"""
+    torch.manual_seed(9)
+    H = heads * D
+    qkv = torch.randn(B * T, 3 * H, requires_grad=True)
+    mask = torch.ones(B, T, dtype=torch.long)
+    for b in range(B):
+        mask[b, T - 2 * b - 1:] = 0
+    q, k, v = (qkv[:, i * H:(i + 1) * H].view(B, T, heads, D).transpose(1, 2) for i in range(3))
+    sc = q @ k.transpose(-2, -1) / float(math.sqrt(D))
+    sc = sc - 10000.0 * (1.0 - mask[:, None, None, :].float())
+    pr = F.softmax(sc, dim=-1)
+    ctx_ref = (pr @ v).transpose(1, 2).contiguous().view(B * T, H)
+    dctx = torch.randn(B * T, H)
+    ctx_ref.backward(dctx)
+    qd, md = qkv.detach().to(dev()), mask.to(dev())
+    ctx = torch.zeros(B * T, H, device=dev())
+    probs = torch.zeros(B, heads, T, T, device=dev())
+    a = L.AttnDesc()
+    a.q, a.k, a.v = P(qd), P(qd) + 4 * H, P(qd) + 8 * H
+    a.row_stride, a.head_stride = 3 * H, D
+    a.out, a.out_row_stride, a.out_head_stride = P(ctx), H, D
+    a.mask, a.mask_on_query, a.probs = P(md), 0, P(probs)
+    a.B, a.T, a.heads, a.sqrt_d = B, T, heads, math.sqrt(D)
+    L.check(L.lib().mmvqa_attention(C.byref(a), D, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert_close(ctx, ctx_ref, TOL, "ctx")
+    assert_close(probs.transpose(-1, -2), pr, TOL, "probs")
+    dqkv = torch.zeros(B * T, 3 * H, device=dev())
+    dctxd = dctx.to(dev())
+    a.dout, a.dq, a.dk, a.dv = P(dctxd), P(dqkv), P(dqkv) + 4 * H, P(dqkv) + 8 * H
+    L.check(L.lib().mmvqa_attention(C.byref(a), D, 1, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert_close(dqkv, qkv.grad, TOL, "dqkv")
+
+
+@pytest.mark.parametrize("B,T,es", [(2, 32, 96), (3, 9, 12), (2, 40, 96)])
+def test_attention_realformer(B, T, es):
+    """models/realformer.py:30-45: k,q,v split, residual scores, QUERY-axis mask, prev chain"""
+    torch.manual_seed(10)
+    h = 8
+    kqv = torch.randn(B * T * h, 3 * es, requires_grad=True)
+    prev = (torch.randn(B, T, T, h) * 0.5).requires_grad_(True)
+    mask = torch.ones(B, T, dtype=torch.long)
+    for b in range(B):
+        mask[b, T - b - 1:] = 0
+    x = kqv.view(B, T, h, 3 * es)
+    k, q, v = torch.split(x, es, dim=-1)
+    att = torch.einsum("bihk,bjhk->bijh", q, k) / es ** 0.5 + prev
+    att = att - 10000.0 * (1.0 - mask.unsqueeze(-1).unsqueeze(-1).expand(att.size()).float())
+    pr = F.softmax(att, dim=2)
+    res_ref = torch.einsum("btih,bihs->bths", pr, v).reshape(B * T, h * es)
+    dres, dprev_next = torch.randn(B * T, h * es), torch.randn(B, T, T, h) * 0.1
+    (res_ref * dres).sum().backward(retain_graph=True)
+    g_kqv_1, g_prev_1 = kqv.grad.clone(), prev.grad.clone()
+    kqv.grad = None
+    prev.grad = None
+    ((res_ref * dres).sum() + (att * dprev_next).sum()).backward()
+    kd, md, pd = kqv.detach().to(dev()), mask.to(dev()), prev.detach().to(dev())
+    res = torch.zeros(B * T, h * es, device=dev())
+    probs = torch.zeros(B, h, T, T, device=dev())
+    prev_out = torch.zeros(B, T, T, h, device=dev())
+    a = L.AttnDesc()
+    a.k, a.q, a.v = P(kd), P(kd) + 4 * es, P(kd) + 8 * es
+    a.row_stride, a.head_stride = h * 3 * es, 3 * es
+    a.out, a.out_row_stride, a.out_head_stride = P(res), h * es, es
+    a.mask, a.mask_on_query, a.probs = P(md), 1, P(probs)
+    a.prev_in, a.prev_out = P(pd), P(prev_out)
+    a.B, a.T, a.heads, a.sqrt_d = B, T, h, es ** 0.5
+    L.check(L.lib().mmvqa_attention(C.byref(a), es, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert_close(prev_out, att, 1e-6, "prev_out")
+    assert_close(res, res_ref, TOL, "res")
+    dk = torch.zeros(B * T * h, 3 * es, device=dev())
+    dpo = torch.zeros(B, T, T, h, device=dev())
+    dresd, dpn = dres.to(dev()), dprev_next.to(dev())
+    a.dout, a.dk, a.dq, a.dv = P(dresd), P(dk), P(dk) + 4 * es, P(dk) + 8 * es
+    a.dprev_in, a.dprev_out = P(dpn), P(dpo)
+    L.check(L.lib().mmvqa_attention(C.byref(a), es, 1, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert_close(dk, kqv.grad, TOL, "dkqv")
+    assert_close(dpo, prev.grad, TOL, "dprev")
+
+
+# ----------------------------------------------------------------------------- losses / optimizer
+def test_mlm_loss(golden_dir):
+    torch.manual_seed(11)
+    B, T, V = 4, 16, 30522
+    logits = (torch.randn(B, T, V) * 2).requires_grad_(True)
+    tgt = torch.zeros(B, T, dtype=torch.long)
+    tgt[0, 3], tgt[1, 7], tgt[2, 9], tgt[3, 1] = 17, 30521, 5, 1234
+    loss_ref, lp = O.mlm_loss(logits, tgt)
+    loss_ref.backward()
+    pred_ref, nc, nm = O.mlm_accuracy(lp, tgt)
+    lg = logits.detach().to(dev()).requires_grad_(True)
+    loss, pred, stats = mmvqa_amd.mlm_loss(lg, tgt.to(dev()))
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+    assert_close(lg.grad, logits.grad, TOL, "dlogits")
+    assert torch.equal(pred.cpu()[tgt > 0], pred_ref)           # index ops bit-exact
+    assert torch.equal(pred.cpu(), lp.argmax(-1))
+    assert int(stats[1]) == nm and int(stats[2]) == nc
+
+
+def test_asl_supcon_golden(golden_dir):
+    import numpy as np
+    g = dict(np.load(f"{golden_dir}/losses.npz"))
+    lg = torch.from_numpy(g["asl_logits"]).to(dev()).requires_grad_(True)
+    l = mmvqa_amd.asl_loss(lg, torch.from_numpy(g["asl_target"]).to(dev()))
+    l.backward()
+    assert abs(float(l) - float(g["asl"])) < 2e-5 * abs(float(g["asl"]))
+    assert_close(lg.grad, torch.from_numpy(g["asl_dlogits"]), TOL, "asl grad")
+    f = torch.from_numpy(g["sc_feat"]).to(dev()).requires_grad_(True)
+    l = mmvqa_amd.supcon_loss(f)
+    l.backward()
+    assert abs(float(l) - float(g["sc"])) < 2e-5 * abs(float(g["sc"]))
+    assert_close(f.grad, torch.from_numpy(g["sc_dfeat"]), TOL, "supcon grad")
+    lg = torch.from_numpy(g["mlm_logits"]).to(dev()).requires_grad_(True)
+    l, pred, _ = mmvqa_amd.mlm_loss(lg, torch.from_numpy(g["mlm_target"]).to(dev()))
+    l.backward()
+    assert abs(float(l) - float(g["mlm"])) < 2e-5 * abs(float(g["mlm"]))
+    assert_close(lg.grad, torch.from_numpy(g["mlm_dlogits"]), TOL, "mlm grad")
+    t = torch.from_numpy(g["mlm_target"])
+    assert np.array_equal(pred.cpu()[t > 0].numpy(), g["mlm_pred"])
+
+
+def test_adam():
+    torch.manual_seed(12)
+    n = 4096 + 8
+    p, g = torch.randn(n), torch.randn(n)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, gd, md, vd = (t.clone().to(dev()) for t in (p, g, m, v))
+    for step in (1, 2, 3):
+        O.adam_step(p, g, m, v, step, 2e-5)
+        L.check(L.lib().mmvqa_adam(L.stream_ptr(), P(pd), P(gd), P(md), P(vd), n, 2e-5, 0.9, 0.999, 1e-8, step, 1.0, 0))
+    torch.cuda.synchronize()
+    assert_close(pd, p, 1e-6, "adam p")
+    assert_close(vd, v, 1e-6, "adam v")
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.ones(4))], lr=2e-5)  # same defaults as roco_train.py:90
+    assert ref.defaults["betas"] == (0.9, 0.999) and ref.defaults["eps"] == 1e-8
+
+
+def test_meanpool_l2norm():
+    torch.manual_seed(13)
+    B, T, H = 3, 11, 96
+    h = torch.randn(B, T, H, requires_grad=True)
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, 6:] = 0
+    mask[2, :] = 0
+    ref = O.mean_pooling(h, mask)
+    dp = torch.randn(B, H)
+    ref.backward(dp)
+    hd, md = h.detach().to(dev()), mask.to(dev())
+    out = torch.zeros(B, H, device=dev())
+    L.check(L.lib().mmvqa_meanpool_fwd(L.stream_ptr(), P(hd), P(md), P(out), B, T, H))
+    assert_close(out, ref, TOL, "meanpool")
+    dh = torch.zeros(B, T, H, device=dev())
+    L.check(L.lib().mmvqa_meanpool_bwd(L.stream_ptr(), P(dp.to(dev())), P(md), P(dh), B, T, H, 0))
+    torch.cuda.synchronize()
+    assert_close(dh, h.grad, TOL, "meanpool bwd")
+    x = torch.randn(5, 128, requires_grad=True)
+    y_ref = F.normalize(x, dim=1)
+    dy = torch.randn(5, 128)
+    y_ref.backward(dy)
+    xd = x.detach().to(dev())
+    y, nrm, dx = torch.zeros(5, 128, device=dev()), torch.zeros(5, device=dev()), torch.zeros(5, 128, device=dev())
+    L.check(L.lib().mmvqa_l2norm_fwd(L.stream_ptr(), P(xd), P(y), P(nrm), 5, 128))
+    L.check(L.lib().mmvqa_l2norm_bwd(L.stream_ptr(), P(dy.to(dev())), P(y), P(nrm), P(dx), 5, 128))
+    torch.cuda.synchronize()
+    assert_close(y, y_ref, TOL, "l2norm")
+    assert_close(dx, x.grad, TOL, "l2norm bwd")
