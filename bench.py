@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: samples/s of one full ROCO-MLM training step (BASELINE.json configs[1]):
+resnet152 + transformer, num_vis 5, hidden 768, per-GPU batch 16, 224x224, T=32, fp32;
+forward + MLM loss + backward + (gradient all-reduce) + Adam, dropout active, train-mode BatchNorm,
+inputs resident in HBM.  Prints ONE JSON line (see the driver contract in the task statement).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """threads this process may really use: affinity mask capped by the cgroup CPU quota"""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32-input matrix peak
+B_PER_GPU, T, HW, VOCAB = 16, 32, 224, 30522
+
+
+def make_args():
+    from types import SimpleNamespace
+    return SimpleNamespace(task="MLM", dataset="roco", transformer_model="transformer", cnn_encoder="resnet152",
+                           num_vis=5, hidden_size=768, n_layers=4, heads=12, hidden_dropout_prob=0.3,
+                           vocab_size=VOCAB, use_relu=False, max_position_embeddings=T)
+
+
+def cpu_baseline(seed):
+    """the oracle (CPU restatement, kind 'port') timed on this host: 2 steps of B=4 after 1 warm-up"""
+    from oracle import mmbert_oracle as O
+    from mmvqa_amd import synth
+    torch.manual_seed(seed)
+    cores = min(host_cores(), 32)
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle on {cores} host threads")
+    m = O.OracleModel(O.make_args(**vars(make_args()))).train()
+    opt = torch.optim.Adam(m.parameters(), lr=2e-5)
+    Bc = 4
+    img, ids, seg, mask, tgt = synth.roco_batch(Bc, T, HW, VOCAB, seed=seed)
+
+    def step():
+        opt.zero_grad()
+        loss = O.mlm_loss(m(img, ids, seg, mask), tgt)[0]
+        loss.backward()
+        opt.step()
+
+    step()
+    log("cpu_baseline: warm-up step done")
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        step()
+    dt = time.perf_counter() - t0
+    log(f"cpu_baseline: {n} steps in {dt:.1f}s")
+    return dict(value=Bc * n / dt, unit="samples/s", cores=cores, kind="port",
+                sample=f"{n} training steps of batch {Bc} (same model/shapes, fwd+loss+bwd+Adam) after 1 warm-up")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import mmvqa_amd
+    from mmvqa_amd import synth
+    from mmvqa_amd.ddp import GradReducer
+
+    torch.manual_seed(1234)            # identical initial weights on every rank
+    torch.set_num_threads(min(host_cores(), 16))
+    log("building model (random init on the host)")
+    model = mmvqa_amd.Model(make_args())
+    model.to(dev).train()
+    log(f"model on {dev}: {model.flat_params.numel() / 1e6:.1f} M parameters")
+    model.set_seed(1234 + rank)
+    opt = mmvqa_amd.FusedAdam(model, lr=2e-5)
+    red = GradReducer(model.flat_grads)
+    img, ids, seg, mask, tgt = synth.roco_batch(B_PER_GPU, T, HW, VOCAB, seed=1234 + rank, device=dev)
+
+    def step():
+        logits = model(img, ids, seg, mask)
+        loss, _, stats = mmvqa_amd.mlm_loss(logits, tgt)
+        loss.backward()
+        red.allreduce()
+        opt.step(grad_scale=1.0 / world, zero_grad=True)
+        return stats
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        stats = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms = dt / a.steps * 1e3
+    log(f"timed {a.steps} steps: {ms:.2f} ms/step")
+    value = B_PER_GPU * world * a.steps / dt
+
+    roof = None
+    if not a.no_roofline:
+        model.profile(True)
+        step()
+        torch.cuda.synchronize()
+        pr = model.profile_read()
+        model.profile(False)
+        g = pr["igemm"]
+        ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        roof = dict(bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None, kernel="igemm_kernel (fp32 MFMA implicit GEMM)",
+                    launches_per_step=g["launches"], avg_launch_us=g["ms"] * 1e3 / max(1, g["launches"]),
+                    algorithmic_gflop_per_step=g["flops"] / 1e9,
+                    other_ms_per_step=dict(attention=pr["attention"]["ms"], elementwise=pr["other"]["ms"]))
+
+    out = dict(metric="samples/sec ROCO-MLM pretrain (resnet152+transformer, bs16/GPU, 224^2, seq32)",
+               value=value, unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=ms,
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload="pretrain/roco_train.py MLM-only: resnet152 + transformer(4 layers, 12 heads), "
+                                    "num_vis 5, hidden 768, vocab 30522, per-GPU batch 16, 224x224, T=32; "
+                                    "fwd + log_softmax/NLL + bwd + grad all-reduce + Adam; dropout on, train-mode BN; "
+                                    "random-init weights",
+                           global_batch=B_PER_GPU * world, seq_len=T, parallelism=f"dp{world}",
+                           samples_per_s_per_gpu=value / world, final_loss=float(stats[0])))
+    if roof is not None:
+        out["roofline"] = roof
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(1234)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -199,8 +199,8 @@ int mmvqa_l2norm_bwd(mmvqa_stream_t s, const float* dy, const float* y, const fl
 int mmvqa_supcon_loss(mmvqa_stream_t s, const float* f, float* loss, float* df, int N, int D, float temp,
                       float base_temp, float gscale);
 /* torch.optim.Adam defaults over a flat buffer; g is scaled by gscale first and zeroed when zero_grad != 0 */
-int mmvqa_adam(mmvqa_stream_t s, float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2,
-               float eps, int step, float gscale, int zero_grad);
+int mmvqa_adam(mmvqa_stream_t s, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2,
+               double eps, int step, float gscale, int zero_grad);
 int mmvqa_axpy(mmvqa_stream_t s, float* y, const float* x, float a, long n);
 int mmvqa_colsum(mmvqa_stream_t s, const float* x, int ld, int rows, int cols, float* out);
 int mmvqa_dropout(mmvqa_stream_t s, float* x, long n, float p, uint32_t seed);

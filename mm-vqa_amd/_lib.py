@@ -94,7 +94,7 @@ SIGNATURES = {
     "mmvqa_l2norm_fwd": (_i, [_P, _P, _P, _P, _i, _i]),
     "mmvqa_l2norm_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i]),
     "mmvqa_supcon_loss": (_i, [_P, _P, _P, _P, _i, _i, _f, _f, _f]),
-    "mmvqa_adam": (_i, [_P, _P, _P, _P, _P, _l, _f, _f, _f, _f, _i, _f, _i]),
+    "mmvqa_adam": (_i, [_P, _P, _P, _P, _P, _l, _d, _d, _d, _d, _i, _f, _i]),
     "mmvqa_axpy": (_i, [_P, _P, _P, _f, _l]),
     "mmvqa_colsum": (_i, [_P, _P, _i, _i, _i, _P]),
     "mmvqa_dropout": (_i, [_P, _P, _l, _f, _u32]),

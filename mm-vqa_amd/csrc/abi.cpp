@@ -135,8 +135,8 @@ int mmvqa_supcon_loss(mmvqa_stream_t s, const float* f, float* loss, float* df, 
                       float base_temp, float gscale) {
   return k_supcon(ST(s), f, loss, df, N, D, temp, base_temp, gscale);
 }
-int mmvqa_adam(mmvqa_stream_t s, float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2,
-               float eps, int step, float gscale, int zero_grad) {
+int mmvqa_adam(mmvqa_stream_t s, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2,
+               double eps, int step, float gscale, int zero_grad) {
   return k_adam(ST(s), p, g, m, v, n, lr, b1, b2, eps, step, gscale, zero_grad);
 }
 int mmvqa_axpy(mmvqa_stream_t s, float* y, const float* x, float a, long n) { return k_axpy(ST(s), y, x, a, n); }

@@ -697,21 +697,20 @@ __global__ void supcon_kernel(const float* __restrict__ f, float* __restrict__ l
 
 // =========================================================================== Adam (torch defaults; roco_train.py:90)
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n4, float lr, float b1, float b2, float eps,
-                            float bc1, float bc2_sqrt, float gscale, int zero_grad) {
+                            float* __restrict__ v, long n4, float step_size, float b1, float omb1, float b2,
+                            float omb2, float eps, float bc2_sqrt, float gscale, int zero_grad) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long stride = (long)gridDim.x * blockDim.x;
-  const float step = lr / bc1;
   for (; i < n4; i += stride) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<f32x4*>(g)[i];
     f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float gg = gv[e] * gscale;
-      mv[e] = mv[e] * b1 + gg * (1.f - b1);
-      vv[e] = vv[e] * b2 + gg * gg * (1.f - b2);
+      mv[e] = mv[e] + (gg - mv[e]) * omb1;           // exp_avg.lerp_(grad, 1 - beta1)
+      vv[e] = vv[e] * b2 + gg * gg * omb2;           // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
       float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
-      pv[e] = pv[e] - step * (mv[e] / denom);
+      pv[e] = pv[e] - step_size * (mv[e] / denom);
     }
     reinterpret_cast<f32x4*>(p)[i] = pv;
     reinterpret_cast<f32x4*>(m)[i] = mv;
@@ -907,13 +906,14 @@ int k_supcon(hipStream_t st, const float* f, float* loss, float* df, int N, int 
   return MMVQA_OK;
 }
 
-int k_adam(hipStream_t st, float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+int k_adam(hipStream_t st, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
            int step, float gscale, int zero_grad) {
   if (n % 4 != 0) return mmvqa_set_error(MMVQA_ERR_ARG, "adam: n must be a multiple of 4");
-  float bc1 = 1.0f - powf(b1, (float)step);
-  float bc2s = sqrtf(1.0f - powf(b2, (float)step));
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, st, p, g, m, v, n / 4, lr, b1, b2,
-                     eps, bc1, bc2s, gscale, zero_grad);
+  // bias corrections and (1 - beta) in double, as torch.optim.Adam computes them from Python floats
+  const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, st, p, g, m, v, n / 4,
+                     (float)(lr / bc1), (float)b1, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps,
+                     (float)sqrt(bc2), gscale, zero_grad);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }

@@ -40,7 +40,7 @@ int k_l2norm_fwd(hipStream_t st, const float* x, float* y, float* nrm, int rows,
 int k_l2norm_bwd(hipStream_t st, const float* dy, const float* y, const float* nrm, float* dx, int rows, int D);
 int k_supcon(hipStream_t st, const float* f, float* loss, float* df, int N, int D, float temp, float base_temp,
              float gscale);
-int k_adam(hipStream_t st, float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+int k_adam(hipStream_t st, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
            int step, float gscale, int zero_grad);
 int k_axpy(hipStream_t st, float* y, const float* x, float a, long n);
 int k_colsum(hipStream_t st, const float* x, int ld, int rows, int cols, float* out);

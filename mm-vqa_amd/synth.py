@@ -18,7 +18,8 @@ def roco_batch(B, T=32, hw=224, vocab=30522, seed=1234, device="cpu", mlm_prob=0
     tgt = torch.zeros(B, T, dtype=torch.long)
     lo = min(1000, max(1, vocab // 2))
     for b in range(B):
-        n = int(torch.randint(4, max(5, T - 8 + 1), (1,), generator=g))
+        n_max = T - 8                      # [CLS] + 5 visual slots + 2x[SEP] are always present
+        n = int(torch.randint(min(4, n_max), n_max + 1, (1,), generator=g))
         cap = torch.randint(lo, vocab, (n,), generator=g)
         m = torch.rand(n, generator=g) < mlm_prob
         ids[b, 0] = 101 % vocab

