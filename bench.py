@@ -52,7 +52,7 @@ def make_args():
 
 
 def cpu_baseline(seed):
-    """the oracle (CPU restatement, kind 'port') timed on this host: 2 steps of B=4 after 1 warm-up"""
+    """the oracle (CPU restatement, kind 'port') timed on this host: 10 steps of B=4 after 1 warm-up"""
     from oracle import mmbert_oracle as O
     from mmvqa_amd import synth
     torch.manual_seed(seed)
@@ -73,7 +73,7 @@ def cpu_baseline(seed):
     step()
     log("cpu_baseline: warm-up step done")
     t0 = time.perf_counter()
-    n = 2
+    n = 10
     for _ in range(n):
         step()
     dt = time.perf_counter() - t0

