@@ -31,13 +31,40 @@ typedef mmvqa_gemm_desc GemmParams;
 typedef mmvqa_attn_desc AttnParams;
 
 // --------------------------------------------------------------------------- device math
+// SERF(x) = x * erf(softplus(min(x,50)))  (models/serf.py:23-24).  softplus >= 0, so erf is only needed
+// on [0, inf): odd Taylor polynomial below 0.5 (no cancellation for tiny arguments), Abramowitz-Stegun
+// 7.1.28 above (|err| < 3e-7); exp/log on the hardware transcendental unit.  Measured against fp64:
+// max abs error 9e-7 forward / 1e-6 derivative (torch's own fp32 result: 2e-7); ~4x fewer
+// instructions than libm's erff/log1pf/expf, which matters in the tap epilogues (154 M evaluations/step).
+__device__ __forceinline__ float erf_pos(float s) {
+  float t = 1.0f + s * (0.0705230784f + s * (0.0422820123f + s * (0.0092705272f +
+            s * (0.0001520143f + s * (0.0002765672f + s * 0.0000430638f)))));
+  t = t * t; t = t * t; t = t * t; t = t * t;
+  const float big = 1.0f - 1.0f / t;
+  const float s2 = s * s;
+  float pl = -7.5757575757e-4f;                       // -1/1320
+  pl = pl * s2 + 4.6296296296e-3f;                    //  1/216
+  pl = pl * s2 - 2.3809523810e-2f;                    // -1/42
+  pl = pl * s2 + 0.1f;
+  pl = pl * s2 - 0.33333333333f;
+  pl = pl * s2 + 1.0f;
+  const float small = 1.12837916709551257390f * s * pl;
+  return s < 0.5f ? small : big;
+}
+__device__ __forceinline__ void serf_parts(float x, float& e, float& sp) {
+  const float xc = x < 50.f ? x : 50.f;
+  e = __expf(xc);
+  sp = e < 0.01f ? e * (1.0f - e * (0.5f - e * 0.33333333333f)) : __logf(1.0f + e);
+}
+
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
     case ACT_RELU: return x > 0.f ? x : 0.f;
     case ACT_GELU: return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
     case ACT_SERF: {
-      float xc = x < 50.f ? x : 50.f;
-      return x * erff(log1pf(expf(xc)));
+      float e, sp;
+      serf_parts(x, e, sp);
+      return x * erf_pos(sp);
     }
     default: return x;
   }
@@ -53,13 +80,12 @@ __device__ __forceinline__ float act_bwd(int act, float x) {
     }
     case ACT_SERF: {
       // d/dx [x erf(sp(min(x,50)))]; the clamp kills the inner derivative above 50
-      float xc = x < 50.f ? x : 50.f;
-      float e = expf(xc);
-      float sp = log1pf(e);
-      float er = erff(sp);
+      float e, sp;
+      serf_parts(x, e, sp);
+      const float er = erf_pos(sp);
       if (x > 50.f) return er;
-      float sig = e / (1.0f + e);
-      return er + x * 1.12837916709551257390f * expf(-sp * sp) * sig;
+      const float sig = e / (1.0f + e);
+      return er + x * 1.12837916709551257390f * __expf(-sp * sp) * sig;
     }
     default: return 1.f;
   }

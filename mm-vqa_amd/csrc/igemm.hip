@@ -8,55 +8,81 @@
 //  and models/mmbert.py:133-137 linears are all instances.)
 //
 // Tiling: 256 threads = 4 waves (2x2); workgroup tile BMxBN, wave tile (BM/2)x(BN/2) made of
-// 32x32 MFMA tiles; BK = 32, LDS double-buffered, one barrier per K-tile.  Operands whose
-// contraction index is contiguous in memory sit in LDS as [row][k] (stride 36 floats, read
-// as ds_read_b128: conflict-free, see MI355X_MICROARCH LDS table); operands whose row index
-// is contiguous sit as [k][row] and are read with ds_read_b32.  Within an 8-deep k-group lane
+// 32x32 MFMA tiles; K-tile BK (32, or 64 for the small tile), LDS double-buffered, one barrier per
+// K-tile.  Operands whose contraction index is contiguous in memory sit in LDS as [row][k] (stride
+// BK+4 floats, read as ds_read_b128: conflict-free, MI355X_MICROARCH LDS table); operands whose row
+// index is contiguous sit as [k][row] and are read with ds_read_b32.  Within an 8-deep k-group lane
 // half h feeds k = 4h+j at MFMA step j for BOTH operands, so the permuted k order is consistent.
 //
-// Prologues (BatchNorm apply + ReLU, BatchNorm backward) run when a tile is written to LDS;
-// the epilogue fuses bias / activation / dropout / residual / ReLU-mask / per-channel
-// statistics so that BatchNorm never needs its own pass over a feature map.
+// The loaders keep the per-K-tile integer work minimal (round-1 profile: ~600 VALU instructions of
+// index math per 16 MFMAs made the kernel VALU-bound): every thread precomputes a 32-bit element
+// offset and a per-tap validity mask for each of its rows once; per K-tile it only advances
+// (channel, tap) incrementally, reads the tap's offset from a small LDS table and issues
+// unconditional 16-byte loads from a clamped offset (no branches in the load phase); validity is
+// applied with selects when the tile is written to LDS.
+//
+// Prologues (BatchNorm apply + ReLU, BatchNorm backward) run at that LDS write; the epilogue fuses
+// bias / activation / dropout / residual / ReLU-mask / per-channel statistics so that BatchNorm never
+// needs its own pass over a feature map.
+#include <type_traits>
+
 #include "common.h"
 
-#define BK 32
-#define LDK 36  // row stride (floats) of a [row][k] LDS tile
+struct FastDiv {  // q = n / d for 0 <= n < 2^31 (host-computed magic; CUTLASS FastDivmod scheme)
+  uint32_t mul, shr, d;
+};
+struct GemmAux {
+  FastDiv ohw, ow;
+};
+
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+  return f.d == 1 ? n : (int)(__umulhi((uint32_t)n, f.mul) >> f.shr);
+}
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-__device__ __forceinline__ f32x4 apply_pro(int pro, f32x4 v, f32x4 v2, f32x4 c0, f32x4 c1, f32x4 c2) {
-  f32x4 r;
-  if (pro == PRO_AFFINE_RELU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { float t = v[j] * c0[j] + c1[j]; r[j] = t > 0.f ? t : 0.f; }
-  } else if (pro == PRO_DZ) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = v[j] * c0[j] + v2[j] * c1[j] + c2[j];
-  } else if (pro == PRO_AFFINE) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = v[j] * c0[j] + c1[j];
-  } else {
-    r = v;
-  }
-  return r;
+// compile-time loops: the accumulator tiles must only ever be indexed with constants, otherwise the
+// compiler demotes them to scratch memory and re-stores them every K-tile
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int BM, int BN, int KIND, bool NCHW>
-__global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
+#define MAX_TAPS 32
+
+// KS = intra-workgroup split of every K-tile over KS groups of 4 waves (KS*256 threads): for problems
+// with fewer workgroups than CUs it doubles the waves per SIMD (latency hiding) at the price of one
+// LDS reduction at the end.
+template <int BM, int BN, int BK, int KIND, bool NCHW, int KS>
+__global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, const GemmAux x) {
+  constexpr int NT = 256 * KS;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int NA = BM / 32, NB = BN / 32;  // float4 chunks per thread per K-tile
+  constexpr int LDK = BK + 4;
+  constexpr int KQ = BK / 4;                 // float4 per row of a [row][k] tile
+  constexpr int RSTEP = NT / KQ;             // rows covered by one pass of the NT threads
+  constexpr int NA = BM / RSTEP, NB = BN / RSTEP;  // float4 chunks per thread per K-tile ([row][k] form)
   constexpr bool A_ROWK = (KIND != KIND_WGRAD);
   constexpr bool B_ROWK = (KIND == KIND_FWD);
   constexpr int LDA_KM = BM + 4, LDB_KM = BN + 4;
   constexpr int A_TILE = A_ROWK ? BM * LDK : BK * LDA_KM;
   constexpr int B_TILE = B_ROWK ? BN * LDK : BK * LDB_KM;
+  // [k][row] form: BK k-rows x (R/4) float4
+  constexpr int A_X4 = BM / 4, A_KSTEP = NT / A_X4, NA_KM = BK / A_KSTEP;
+  constexpr int B_X4 = BN / 4, B_KSTEP = NT / B_X4, NB_KM = BK / B_KSTEP;
+  constexpr int NAC = A_ROWK ? NA : NA_KM;   // chunks per thread actually used
+  constexpr int NBC = B_ROWK ? NB : NB_KM;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][A_TILE]
   float* Bs = smem + 2 * A_TILE;    // [2][B_TILE]
+  int* taptab = reinterpret_cast<int*>(smem + 2 * A_TILE + 2 * B_TILE);  // [MAX_TAPS]
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = (tid >> 6) & 3, ks = tid >> 8;
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -67,52 +93,110 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
   int kt_end = kt_begin + p.ktiles_per_split;
   if (kt_end > nkt_total) kt_end = nkt_total;
   const int nkt = kt_end - kt_begin;
+  const int k_begin = kt_begin * BK;
 
   const int OHW = p.g_OH * p.g_OW;
   const int taps = p.g_KH * p.g_KW;
+  const int s = p.g_stride;
 
-  // ------------------------------------------------------------------ loader state
-  // A, row-major gather (FWD / DGRAD): per-thread rows (tid>>3)+32r, k-quad tid&7
-  int a_pix[NA], a_y0[NA], a_x0[NA];
-  // A, k-major plain (WGRAD): chunk (krow, x4)
-  constexpr int A_X4 = BM / 4;   // float4 per k-row
-  const int akm_x4 = tid % A_X4, akm_k0 = tid / A_X4;
-  constexpr int A_KSTEP = 256 / A_X4;
+  // ------------------------------------------------------------------ tap offset table (FWD / DGRAD gathers)
+  if (!NCHW && A_ROWK && tid < MAX_TAPS) {
+    int t = tid < taps ? tid : 0;
+    int kh = t / p.g_KW, kw = t - kh * p.g_KW;
+    int off = (KIND == KIND_FWD) ? (kh * p.g_SW + kw) * p.a_ld : -((kh / s) * p.g_SW + (kw / s)) * p.a_ld;
+    taptab[tid] = off;
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ A loader state
+  const int a_kq = (tid % KQ) * 4;           // k offset of this thread's float4 inside a [row][k] tile
+  const int a_r0 = tid / KQ;
+  int a_base[NAC];                            // element offset of (row, tap 0) / of (k-row, i)
+  uint32_t a_mask[NAC];                       // per-tap validity (gather) or 0/1 (plain)
+  int a_c = 0, a_tap = 0;                     // channel / tap of this thread's k (gather form)
+  int a_pix[NAC], a_y0[NAC], a_x0[NAC];       // NCHW stem only
   f32x4 ac0 = {1, 1, 1, 1}, ac1 = {0, 0, 0, 0}, ac2 = {0, 0, 0, 0};
+  const int akm_x4 = tid % A_X4, akm_k0 = tid / A_X4;
   if constexpr (A_ROWK) {
+    {
+      int k = k_begin + a_kq;
+      if (taps > 1) { a_tap = k / p.g_Cs; a_c = k - a_tap * p.g_Cs; } else { a_c = k; a_tap = (k >= p.g_Cs) ? 1 : 0; }
+    }
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
-      int row = m0 + (tid >> 3) + 32 * r;
+      const int row = m0 + a_r0 + RSTEP * r;
+      a_base[r] = 0; a_mask[r] = 0; a_pix[r] = 0; a_y0[r] = -(1 << 24); a_x0[r] = -(1 << 24);
       if (row < p.M) {
         int n = row / OHW, rem = row - n * OHW;
         int oy = rem / p.g_OW, ox = rem - oy * p.g_OW;
-        a_pix[r] = n * p.g_SH * p.g_SW;
-        if (KIND == KIND_FWD) { a_y0[r] = oy * p.g_stride - p.g_pad; a_x0[r] = ox * p.g_stride - p.g_pad; }
-        else { a_y0[r] = oy + p.g_pad; a_x0[r] = ox + p.g_pad; }
-        if (NCHW) a_pix[r] = n;  // image index; channel planes are resolved per element
-      } else {
-        a_pix[r] = 0; a_y0[r] = -(1 << 24); a_x0[r] = -(1 << 24);
+        if constexpr (NCHW) {
+          a_pix[r] = n; a_y0[r] = oy * s - p.g_pad; a_x0[r] = ox * s - p.g_pad;
+        } else if (KIND == KIND_FWD) {
+          int y0 = oy * s - p.g_pad, x0 = ox * s - p.g_pad;
+          a_base[r] = ((n * p.g_SH + y0) * p.g_SW + x0) * p.a_ld;
+          uint32_t mk = 0;
+          for (int t = 0; t < taps; ++t) {
+            int kh = t / p.g_KW, kw = t - kh * p.g_KW;
+            int sy = y0 + kh, sx = x0 + kw;
+            if (sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW) mk |= 1u << t;
+          }
+          a_mask[r] = mk;
+        } else {
+          int ty = oy + p.g_pad, tx = ox + p.g_pad;
+          int qy = ty / s, ry = ty - qy * s, qx = tx / s, rx = tx - qx * s;
+          a_base[r] = ((n * p.g_SH + qy) * p.g_SW + qx) * p.a_ld;
+          uint32_t mk = 0;
+          for (int t = 0; t < taps; ++t) {
+            int kh = t / p.g_KW, kw = t - kh * p.g_KW;
+            int sy = qy - kh / s, sx = qx - kw / s;
+            if ((kh % s) == ry && (kw % s) == rx && sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW) mk |= 1u << t;
+          }
+          a_mask[r] = mk;
+        }
       }
     }
   } else {
-    // channel = output row index i: loop invariant
-    int i = m0 + akm_x4 * 4;
-    if (p.a_pro != PRO_NONE && i < p.M) {
+    const int i = m0 + akm_x4 * 4;
+#pragma unroll
+    for (int r = 0; r < NA_KM; ++r) {
+      a_base[r] = (k_begin + akm_k0 + A_KSTEP * r) * p.a_ld + i;   // advanced by BK*a_ld per K-tile
+      a_mask[r] = (i < p.M) ? 1u : 0u;
+    }
+    if (p.a_pro != PRO_NONE && i < p.M) {   // channel = output row index i: loop invariant
       ac0 = ld4(p.a_c0 + i); ac1 = ld4(p.a_c1 + i);
       if (p.a_pro == PRO_DZ) ac2 = ld4(p.a_c2 + i);
     }
   }
 
-  // B loaders
-  constexpr int B_X4 = BN / 4;
+  // ------------------------------------------------------------------ B loader state
+  const int b_kq = (tid % KQ) * 4, b_r0 = tid / KQ;
   const int bkm_x4 = tid % B_X4, bkm_k0 = tid / B_X4;
-  constexpr int B_KSTEP = 256 / B_X4;
+  int b_base[NBC];
+  uint32_t b_ok0[NBC];
+  int b_co[NBC], b_tap[NBC];                  // DGRAD: (output channel, tap) of each k-row
   f32x4 bc0 = {1, 1, 1, 1}, bc1 = {0, 0, 0, 0};
-  int b_kh = 0, b_kw = 0, b_ci = 0;   // WGRAD gather: tap/channel of this thread's 4 columns
-  int b_dy[4], b_dx[4], b_cc[4];      // NCHW WGRAD: per-element tap decode
+  int b_kh = 0, b_kw = 0, b_ci = 0;           // WGRAD gather: tap/channel of this thread's 4 columns
+  int b_dy[4], b_dx[4], b_cc[4];              // NCHW WGRAD: per-element tap decode
   bool b_colvalid = true;
-  if constexpr (KIND == KIND_WGRAD) {
-    int nn = n0 + bkm_x4 * 4;
+  if constexpr (KIND == KIND_FWD) {
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const int n = n0 + b_r0 + RSTEP * r;
+      b_ok0[r] = n < p.N;
+      b_base[r] = (n < p.N ? n : 0) * p.b_ld + b_kq + k_begin;   // advanced by BK per K-tile
+    }
+  } else if constexpr (KIND == KIND_DGRAD) {
+    const int n = n0 + bkm_x4 * 4;
+    b_colvalid = n < p.N;
+#pragma unroll
+    for (int r = 0; r < NB_KM; ++r) {
+      int k = k_begin + bkm_k0 + B_KSTEP * r;
+      if (taps > 1) { b_tap[r] = k / p.g_Cs; b_co[r] = k - b_tap[r] * p.g_Cs; }
+      else { b_tap[r] = (k >= p.g_Cs) ? 1 : 0; b_co[r] = k; }
+      b_base[r] = n; b_ok0[r] = 1;
+    }
+  } else {
+    const int nn = n0 + bkm_x4 * 4;
     b_colvalid = nn < p.N;
     if constexpr (!NCHW) {
       int tap = nn / p.g_Cs;
@@ -129,51 +213,57 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
         if (kk >= p.N) b_dy[j] = -(1 << 24);
       }
     }
+#pragma unroll
+    for (int r = 0; r < NB_KM; ++r) { b_base[r] = k_begin + bkm_k0 + B_KSTEP * r; b_ok0[r] = 1; }  // pixel index
   }
 
-  f32x4 ra[NA], ra2[NA], rb[NB];
-  unsigned a_ok = 0, b_ok = 0;  // bit r: chunk r holds real data (prologue applies)
+  f32x4 ra[NAC], ra2[NAC], rb[NBC];
+  uint32_t a_ok = 0, b_ok = 0;   // bit r: chunk r holds real data
 
-  auto load_tile = [&](int kt) {
-    const int kbase = kt * BK;
-    // ---------------- A
-    if constexpr (A_ROWK) {
-      const int k = kbase + (tid & 7) * 4;
-      a_ok = 0;
-      if constexpr (!NCHW) {
-        int tap = 0, c = k;
-        if (taps > 1) { tap = k / p.g_Cs; c = k - tap * p.g_Cs; }
-        int kh = 0, kw = tap;
-        if (p.g_KW > 1 && taps > 1) { kh = tap / p.g_KW; kw = tap - kh * p.g_KW; }
-        else if (taps > 1) { kh = tap; kw = 0; }
-        const bool kvalid = k < p.K;
-        if (p.a_pro != PRO_NONE && kvalid) {
-          ac0 = ld4(p.a_c0 + c); ac1 = ld4(p.a_c1 + c);
-          if (p.a_pro == PRO_DZ) ac2 = ld4(p.a_c2 + c);
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // branch-free advance of (channel, tap) by one K-tile
+  const int adv_tap = BK / p.g_Cs, adv_c = BK - adv_tap * p.g_Cs;
+
+  // The whole K loop is instantiated per prologue mode so that its body is straight-line code
+  // (loads -> MFMAs -> LDS writes in ONE basic block): the compiler can then slot the address
+  // arithmetic and the prologue math between the 64-cycle MFMAs instead of running them serially.
+  auto run = [&](auto APRO_T, auto BPRO_T) __attribute__((always_inline)) {
+    constexpr int APRO = decltype(APRO_T)::value;
+    constexpr int BPRO = decltype(BPRO_T)::value;
+    constexpr bool A_TWO = (APRO == PRO_DZ);
+
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
+      if constexpr (A_ROWK && !NCHW) {
+        const bool kvalid = a_tap < taps;
+        const int toff = taptab[kvalid ? a_tap : 0];
+        if constexpr (APRO != PRO_NONE) {
+          const int cc = kvalid ? a_c : 0;
+          ac0 = ld4(p.a_c0 + cc); ac1 = ld4(p.a_c1 + cc);
+          if constexpr (APRO == PRO_DZ) ac2 = ld4(p.a_c2 + cc);
         }
+        a_ok = 0;
 #pragma unroll
         for (int r = 0; r < NA; ++r) {
-          int sy, sx; bool ok = kvalid;
-          if (KIND == KIND_FWD) { sy = a_y0[r] + kh; sx = a_x0[r] + kw; }
-          else {
-            int ty = a_y0[r] - kh, tx = a_x0[r] - kw;
-            if (p.g_stride == 1) { sy = ty; sx = tx; }
-            else if (p.g_stride == 2) { ok = ok && (((ty | tx) & 1) == 0); sy = ty >> 1; sx = tx >> 1; }
-            else { sy = ty / p.g_stride; sx = tx / p.g_stride;
-                   ok = ok && (sy * p.g_stride == ty) && (sx * p.g_stride == tx); }
-          }
-          ok = ok && sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW;
-          f32x4 v = {0, 0, 0, 0}, v2 = {0, 0, 0, 0};
-          if (ok) {
-            size_t off = (size_t)(a_pix[r] + sy * p.g_SW + sx) * p.a_ld + c;
-            v = ld4(p.A + off);
-            if (KIND != KIND_FWD && p.a_pro == PRO_DZ) v2 = ld4(p.A2 + off);
-            a_ok |= 1u << r;
-          }
-          ra[r] = v; ra2[r] = v2;
+          const bool ok = kvalid && ((a_mask[r] >> (a_tap & 31)) & 1u);
+          const int off = ok ? a_base[r] + toff + a_c : 0;
+          ra[r] = ld4(p.A + off);
+          if constexpr (A_TWO) ra2[r] = ld4(p.A2 + off);
+          a_ok |= (ok ? 1u : 0u) << r;
         }
-      } else {
+        a_c += adv_c; a_tap += adv_tap;
+        const bool wrap = a_c >= p.g_Cs;
+        a_c = wrap ? a_c - p.g_Cs : a_c;
+        a_tap = wrap ? a_tap + 1 : a_tap;
+      } else if constexpr (A_ROWK && NCHW) {
         // stem: NCHW source, scalar gather, K index = (kh*KW+kw)*Cs + c
+        const int k = kt * BK + a_kq;
         int ekh[4], ekw[4], ec[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -183,6 +273,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
           ekh[j] = tap / p.g_KW; ekw[j] = tap - ekh[j] * p.g_KW;
           if (kk >= p.K) ekh[j] = -(1 << 24);
         }
+        a_ok = ~0u;
 #pragma unroll
         for (int r = 0; r < NA; ++r) {
           f32x4 v = {0, 0, 0, 0};
@@ -194,151 +285,136 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
           }
           ra[r] = v;
         }
-      }
-    } else {
-      // WGRAD A': element (k = pixel, i = channel) at A[k*a_ld + i]
-      a_ok = 0;
-      const int i = m0 + akm_x4 * 4;
+      } else {
+        // WGRAD A': element (k = pixel, i = channel) at A[k*a_ld + i]
+        a_ok = 0;
+        const int kk0 = kt * BK + akm_k0;
 #pragma unroll
-      for (int r = 0; r < NA; ++r) {
-        int k = kbase + akm_k0 + A_KSTEP * r;
-        f32x4 v = {0, 0, 0, 0}, v2 = {0, 0, 0, 0};
-        if (k < p.K && i < p.M) {
-          size_t off = (size_t)k * p.a_ld + i;
-          v = ld4(p.A + off);
-          if (p.a_pro == PRO_DZ) v2 = ld4(p.A2 + off);
-          a_ok |= 1u << r;
+        for (int r = 0; r < NA_KM; ++r) {
+          const bool ok = a_mask[r] && (kk0 + A_KSTEP * r < p.K);
+          const int off = ok ? a_base[r] : 0;
+          ra[r] = ld4(p.A + off);
+          if constexpr (A_TWO) ra2[r] = ld4(p.A2 + off);
+          a_ok |= (ok ? 1u : 0u) << r;
+          a_base[r] += BK * p.a_ld;
         }
-        ra[r] = v; ra2[r] = v2;
       }
-    }
-    // ---------------- B
-    if constexpr (KIND == KIND_FWD) {
-      const int k = kbase + (tid & 7) * 4;
+      // ---------------- B
+      if constexpr (KIND == KIND_FWD) {
+        const int k = kt * BK + b_kq;
+        b_ok = 0;
+        if constexpr (!NCHW) {
+          const bool kvalid = k < p.K;
 #pragma unroll
-      for (int r = 0; r < NB; ++r) {
-        int n = n0 + (tid >> 3) + 32 * r;
-        f32x4 v = {0, 0, 0, 0};
-        if (n < p.N) {
-          const float* src = p.B + (size_t)n * p.b_ld + k;
-          if constexpr (!NCHW) {
-            if (k < p.K) v = ld4(src);
-          } else {
+          for (int r = 0; r < NB; ++r) {
+            const bool ok = kvalid && b_ok0[r];
+            rb[r] = ld4(p.B + (ok ? b_base[r] : 0));
+            b_ok |= (ok ? 1u : 0u) << r;
+            b_base[r] += BK;
+          }
+        } else {
+          b_ok = ~0u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (k + j < p.K) v[j] = src[j];
+          for (int r = 0; r < NB; ++r) {
+            f32x4 v = {0, 0, 0, 0};
+            if (b_ok0[r]) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) if (k + j < p.K) v[j] = p.B[b_base[r] + j];
+            }
+            rb[r] = v;
+            b_base[r] += BK;
           }
         }
-        rb[r] = v;
-      }
-    } else if constexpr (KIND == KIND_DGRAD) {
-      const int n = n0 + bkm_x4 * 4;
+      } else if constexpr (KIND == KIND_DGRAD) {
+        b_ok = 0;
 #pragma unroll
-      for (int r = 0; r < NB; ++r) {
-        int k = kbase + bkm_k0 + B_KSTEP * r;
-        f32x4 v = {0, 0, 0, 0};
-        if (k < p.K && n < p.N) {
-          int tap = 0, co = k;
-          if (taps > 1) { tap = k / p.g_Cs; co = k - tap * p.g_Cs; }
-          v = ld4(p.B + (size_t)co * p.b_ld + (size_t)tap * p.b_tapstride + n);
+        for (int r = 0; r < NB_KM; ++r) {
+          const bool ok = b_colvalid && (b_tap[r] < taps);
+          const int off = ok ? b_co[r] * p.b_ld + b_tap[r] * p.b_tapstride + b_base[r] : 0;
+          rb[r] = ld4(p.B + off);
+          b_ok |= (ok ? 1u : 0u) << r;
+          b_co[r] += adv_c; b_tap[r] += adv_tap;
+          const bool wrap = b_co[r] >= p.g_Cs;
+          b_co[r] = wrap ? b_co[r] - p.g_Cs : b_co[r];
+          b_tap[r] = wrap ? b_tap[r] + 1 : b_tap[r];
         }
-        rb[r] = v;
-      }
-    } else {
-      b_ok = 0;
+      } else {
+        b_ok = 0;
 #pragma unroll
-      for (int r = 0; r < NB; ++r) {
-        int m = kbase + bkm_k0 + B_KSTEP * r;
-        f32x4 v = {0, 0, 0, 0};
-        if (m < p.K && b_colvalid) {
-          int n = m / OHW, rem = m - n * OHW;
-          int oy = rem / p.g_OW, ox = rem - oy * p.g_OW;
+        for (int r = 0; r < NB_KM; ++r) {
+          const int m = b_base[r];
+          b_base[r] += BK;
+          const int n = fdiv(m, x.ohw), rem = m - n * OHW;
+          const int oy = fdiv(rem, x.ow), ox = rem - oy * p.g_OW;
           if constexpr (!NCHW) {
-            int sy = oy * p.g_stride - p.g_pad + b_kh, sx = ox * p.g_stride - p.g_pad + b_kw;
-            if (sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW) {
-              v = ld4(p.B + (size_t)((n * p.g_SH + sy) * p.g_SW + sx) * p.b_ld + b_ci);
-              b_ok |= 1u << r;
-            }
+            const int sy = oy * s - p.g_pad + b_kh, sx = ox * s - p.g_pad + b_kw;
+            const bool ok = (m < p.K) && b_colvalid && sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW;
+            const int off = ok ? ((n * p.g_SH + sy) * p.g_SW + sx) * p.b_ld + b_ci : 0;
+            rb[r] = ld4(p.B + off);
+            b_ok |= (ok ? 1u : 0u) << r;
           } else {
+            f32x4 v = {0, 0, 0, 0};
+            if (m < p.K) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              int sy = oy * p.g_stride - p.g_pad + b_dy[j], sx = ox * p.g_stride - p.g_pad + b_dx[j];
-              if (sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW)
-                v[j] = p.B[((size_t)(n * p.g_Cs + b_cc[j]) * p.g_SH + sy) * p.g_SW + sx];
+              for (int j = 0; j < 4; ++j) {
+                int sy = oy * s - p.g_pad + b_dy[j], sx = ox * s - p.g_pad + b_dx[j];
+                if (sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW)
+                  v[j] = p.B[((size_t)(n * p.g_Cs + b_cc[j]) * p.g_SH + sy) * p.g_SW + sx];
+              }
             }
+            rb[r] = v;
+            b_ok = ~0u;
           }
         }
-        rb[r] = v;
       }
-    }
-  };
+    };
 
-  auto store_tile = [&](int buf, int kt) {
-    float* as = As + buf * A_TILE;
-    float* bs = Bs + buf * B_TILE;
-    if constexpr (A_ROWK) {
-      const int kq = (tid & 7) * 4;
-      const int k = kt * BK + kq;
-#pragma unroll
-      for (int r = 0; r < NA; ++r) {
+    // registers -> LDS (+ prologues) for ONE chunk c (A chunks first, then B); selects only, no branches
+    auto store_chunk = [&](int buf, int kt, int c) __attribute__((always_inline)) {
+      float* as = As + buf * A_TILE;
+      float* bs = Bs + buf * B_TILE;
+      if (c < NAC) {
+        const int r = c;
         f32x4 v = ra[r];
-        if (!NCHW && p.a_pro != PRO_NONE && ((a_ok >> r) & 1)) v = apply_pro(p.a_pro, v, ra2[r], ac0, ac1, ac2);
-        if (!NCHW) {
+        const bool ok = (a_ok >> r) & 1u;
+        if constexpr (!(NCHW && A_ROWK)) {   // (the stem's gathered image operand is zero-filled, no prologue)
+          if constexpr (APRO == PRO_AFFINE_RELU) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) if (k + j >= p.K) v[j] = 0.f;
+            for (int j = 0; j < 4; ++j) { float t = v[j] * ac0[j] + ac1[j]; v[j] = t > 0.f ? t : 0.f; }
+          } else if constexpr (APRO == PRO_DZ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] * ac0[j] + ra2[r][j] * ac1[j] + ac2[j];
+          }
+          // ragged K / M (vocab-sized dimension): elements of the float4 beyond the end are zeroed
+          const int e0 = A_ROWK ? (kt * BK + a_kq) : (m0 + akm_x4 * 4);
+          const int lim = A_ROWK ? p.K : p.M;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (ok && (e0 + j < lim)) ? v[j] : 0.f;
         }
-        *reinterpret_cast<f32x4*>(&as[((tid >> 3) + 32 * r) * LDK + kq]) = v;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < NA; ++r) {
-        f32x4 v = ra[r];
-        if (p.a_pro != PRO_NONE && ((a_ok >> r) & 1)) {
-          v = apply_pro(p.a_pro, v, ra2[r], ac0, ac1, ac2);
-          const int i = m0 + akm_x4 * 4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) if (i + j >= p.M) v[j] = 0.f;
+        if constexpr (A_ROWK) {
+          *reinterpret_cast<f32x4*>(&as[(a_r0 + RSTEP * r) * LDK + a_kq]) = v;
+        } else {
+          *reinterpret_cast<f32x4*>(&as[(akm_k0 + A_KSTEP * r) * LDA_KM + akm_x4 * 4]) = v;
         }
-        *reinterpret_cast<f32x4*>(&as[(akm_k0 + A_KSTEP * r) * LDA_KM + akm_x4 * 4]) = v;
-      }
-    }
-    if constexpr (B_ROWK) {
-      const int kq = (tid & 7) * 4;
-#pragma unroll
-      for (int r = 0; r < NB; ++r)
-        *reinterpret_cast<f32x4*>(&bs[((tid >> 3) + 32 * r) * LDK + kq]) = rb[r];
-    } else {
-#pragma unroll
-      for (int r = 0; r < NB; ++r) {
+      } else {
+        const int r = c - NAC;
         f32x4 v = rb[r];
-        if (KIND == KIND_WGRAD && !NCHW && p.b_pro != PRO_NONE && ((b_ok >> r) & 1))
-          v = apply_pro(p.b_pro, v, v, bc0, bc1, bc1);
-        *reinterpret_cast<f32x4*>(&bs[(bkm_k0 + B_KSTEP * r) * LDB_KM + bkm_x4 * 4]) = v;
+        const bool ok = (b_ok >> r) & 1u;
+        if constexpr (KIND == KIND_WGRAD && !NCHW && BPRO == PRO_AFFINE_RELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { float t = v[j] * bc0[j] + bc1[j]; v[j] = t > 0.f ? t : 0.f; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
+        if constexpr (B_ROWK) {
+          *reinterpret_cast<f32x4*>(&bs[(b_r0 + RSTEP * r) * LDK + b_kq]) = v;
+        } else {
+          *reinterpret_cast<f32x4*>(&bs[(bkm_k0 + B_KSTEP * r) * LDB_KM + bkm_x4 * 4]) = v;
+        }
       }
-    }
-  };
+    };
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  if (nkt > 0) {
-    load_tile(kt_begin);
-    store_tile(0, kt_begin);
-  }
-  __syncthreads();
-
-  for (int t = 0; t < nkt; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nkt) load_tile(kt_begin + t + 1);
-    const float* as = As + buf * A_TILE;
-    const float* bs = Bs + buf * B_TILE;
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      f32x4 fa[TM], fb[TN];
+    auto read_frags = [&](const float* as, const float* bs, int kg, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if constexpr (A_ROWK) {
@@ -357,24 +433,118 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
           for (int j = 0; j < 4; ++j) fb[i][j] = bs[(kg * 8 + lh * 4 + j) * LDB_KM + wn0 + i * 32 + li];
         }
       }
+    };
+
+    constexpr int NC = NAC + NBC;
+    constexpr int NKG = BK / 8 / KS;                      // k-groups (8 deep) per wave per K-tile
+    constexpr int K0 = NKG / 2;                           // first k-group after which chunks are written
+    constexpr int PER = (NC + (NKG - K0) - 1) / (NKG - K0);
+
+    if (nkt > 0) {
+      load_tile(kt_begin);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+      for (int c = 0; c < NC; ++c) store_chunk(0, kt_begin, c);
     }
-    if (t + 1 < nkt) store_tile(buf ^ 1, kt_begin + t + 1);
     __syncthreads();
+
+    // Software pipeline of one K-tile (single barrier):
+    //   fragments of k-group kk+1 are read from LDS while the MFMAs of kk run;
+    //   the global loads of tile t+1 are issued behind the first MFMA group (their address
+    //   arithmetic runs in the shadow of the matrix pipe);
+    //   the LDS writes of tile t+1 (other buffer: last read one barrier ago) are spread over the
+    //   second half of the MFMA groups instead of forming a bubble before the barrier.
+    if constexpr (TM * TN == 1) {
+      for (int t = 0; t < nkt; ++t) {
+        const int buf = t & 1;
+        const float* as = As + buf * A_TILE;
+        const float* bs = Bs + buf * B_TILE;
+        f32x4 fa[2][TM], fb[2][TN];
+        read_frags(as, bs, ks, fa[0], fb[0]);
+  #pragma unroll
+        for (int kk = 0; kk < NKG; ++kk) {
+          if (kk + 1 < NKG) read_frags(as, bs, (kk + 1) * KS + ks, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+  #pragma unroll
+          for (int j = 0; j < 4; ++j)
+  #pragma unroll
+            for (int a = 0; a < TM; ++a)
+  #pragma unroll
+              for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][a][j], fb[kk & 1][b][j], acc[a][b], 0, 0, 0);
+          if (kk == 0) load_tile(kt_begin + t + 1);   // unconditional: past the end everything is masked
+          if (kk >= K0) {
+  #pragma unroll
+            for (int c = (kk - K0) * PER; c < (kk - K0 + 1) * PER && c < NC; ++c) store_chunk(buf ^ 1, kt_begin + t + 1, c);
+          }
+        }
+        __syncthreads();
+      }
+    } else {
+      // large wave tiles (16-64 MFMAs per k-group, two workgroups per CU): plain order, the second
+      // resident workgroup covers the LDS-write/barrier bubble
+      for (int t = 0; t < nkt; ++t) {
+        const int buf = t & 1;
+        const float* as = As + buf * A_TILE;
+        const float* bs = Bs + buf * B_TILE;
+        load_tile(kt_begin + t + 1);
+#pragma unroll
+        for (int kk = 0; kk < NKG; ++kk) {
+          f32x4 fa[TM], fb[TN];
+          read_frags(as, bs, kk * KS + ks, fa, fb);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+              for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) store_chunk(buf ^ 1, kt_begin + t + 1, c);
+        __syncthreads();
+      }
+    }
+  };
+
+  {
+    using I0 = std::integral_constant<int, PRO_NONE>;
+    using I1 = std::integral_constant<int, PRO_AFFINE_RELU>;
+    using I2 = std::integral_constant<int, PRO_DZ>;
+    if constexpr (KIND == KIND_FWD) {
+      if (p.a_pro == PRO_AFFINE_RELU && !NCHW) run(I1{}, I0{}); else run(I0{}, I0{});
+    } else if constexpr (KIND == KIND_DGRAD) {
+      if (p.a_pro == PRO_DZ) run(I2{}, I0{}); else run(I0{}, I0{});
+    } else {
+      if (p.a_pro == PRO_DZ) {
+        if (p.b_pro == PRO_AFFINE_RELU && !NCHW) run(I2{}, I1{}); else run(I2{}, I0{});
+      } else {
+        if (p.b_pro == PRO_AFFINE_RELU && !NCHW) run(I0{}, I1{}); else run(I0{}, I0{});
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ intra-workgroup K reduction
+  if constexpr (KS > 1) {
+    float* red = smem;   // the tile buffers are free after the loop's last barrier
+    if (ks == 1) {
+      static_for<TM * TN * 16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        red[(wave * TM * TN * 16 + i) * 64 + lane] = acc[i / (TN * 16)][(i / 16) % TN][i % 16];
+      });
+    }
+    __syncthreads();
+    if (ks != 0) return;
+    static_for<TM * TN * 16>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      acc[i / (TN * 16)][(i / 16) % TN][i % 16] += red[(wave * TM * TN * 16 + i) * 64 + lane];
+    });
   }
 
   // ------------------------------------------------------------------ epilogue
   const float inv_hw = p.tap_HW > 0 ? 1.0f / (float)p.tap_HW : 0.f;
   const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.f;
   const int slot = (blockIdx.y + blockIdx.x * 7 + blockIdx.z * 3) & (MMVQA_STAT_SLOTS - 1);
-#pragma unroll
-  for (int b = 0; b < TN; ++b) {
+  static_for<TN>([&](auto bI) {
+    constexpr int b = decltype(bI)::value;
     const int col = n0 + wn0 + b * 32 + li;
     const bool cvalid = col < p.N;
     float bias = (p.bias && cvalid) ? p.bias[col] : 0.f;
@@ -387,12 +557,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
     double s_a = 0.0, s_b = 0.0, s_c = 0.0;
     float cs = 0.f;
     int tap_b = -1; float tap_acc = 0.f;
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
+    static_for<TM>([&](auto aI) {
+      constexpr int a = decltype(aI)::value;
+      static_for<16>([&](auto eI) {
+        constexpr int e = decltype(eI)::value;
         const int row = m0 + wm0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (row >= p.M || !cvalid) continue;
+        if (row >= p.M || !cvalid) return;
         float v = acc[a][b][e] + bias;
         if (p.Cpre) p.Cpre[(size_t)row * p.c_ld + col] = v;
         if (p.epi_mode == EPI_TAP_FWD) {
@@ -403,7 +573,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
             tap_b = bi; tap_acc = 0.f;
           }
           tap_acc += w;
-          continue;
+          return;
         }
         if (p.epi_mode == EPI_TAP_BWD) {
           int bi = row / p.tap_HW;
@@ -433,8 +603,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
           }
         }
         if (p.colsum) cs += v;
-      }
-    }
+      });
+    });
     if (p.epi_mode == EPI_TAP_FWD && tap_b >= 0) atomicAdd(&p.tap_out[(size_t)tap_b * p.N + col], tap_acc);
     if (p.stat1) {
       s_a += __shfl_xor(s_a, 32, 64);
@@ -455,36 +625,57 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams p) {
       cs += __shfl_xor(cs, 32, 64);
       if (lh == 0 && cvalid) atomicAdd(&p.colsum[col], cs);
     }
-  }
+  });
 }
 
 // --------------------------------------------------------------------------- host launch
-template <int BM, int BN, int KIND, bool NCHW>
+static FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  f.d = (uint32_t)d;
+  if (d <= 1) { f.mul = 0; f.shr = 0; f.d = 1; return f; }
+  int lg = 31;
+  while (lg > 0 && !((uint32_t)d >> lg)) --lg;   // floor(log2 d)
+  if (d & (d - 1)) ++lg;                         // ceil(log2 d)
+  const int pw = 31 + lg;
+  const uint64_t m = ((1ull << pw) + (uint64_t)d - 1) / (uint64_t)d;
+  f.mul = (uint32_t)m;
+  f.shr = (uint32_t)(pw - 32);
+  return f;
+}
+
+template <int BM, int BN, int BK, int KIND, bool NCHW, int KS = 1>
 static int launch_cfg(const GemmParams& p, hipStream_t stream) {
   constexpr bool A_ROWK = (KIND != KIND_WGRAD);
   constexpr bool B_ROWK = (KIND == KIND_FWD);
-  constexpr int A_TILE = A_ROWK ? BM * LDK : BK * (BM + 4);
-  constexpr int B_TILE = B_ROWK ? BN * LDK : BK * (BN + 4);
-  constexpr size_t smem = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(float);
+  constexpr int A_TILE = A_ROWK ? BM * (BK + 4) : BK * (BM + 4);
+  constexpr int B_TILE = B_ROWK ? BN * (BK + 4) : BK * (BN + 4);
+  constexpr size_t smem = (size_t)(2 * A_TILE + 2 * B_TILE + MAX_TAPS) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, KIND, NCHW>,
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, KIND, NCHW, KS>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
+  GemmAux x;
+  x.ohw = make_fastdiv(p.g_OH * p.g_OW);
+  x.ow = make_fastdiv(p.g_OW);
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splitk);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, KIND, NCHW>), grid, dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, KIND, NCHW, KS>), grid, dim3(256 * KS), smem, stream, p, x);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
+// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 (BK 64), 4 = 64x128, 5 = 64x64 with 8 waves (K-tile split in 2)
 int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MMVQA_OK;
   if (p.g_KH <= 0) { p.g_KH = p.g_KW = 1; p.g_stride = 1; p.g_pad = 0; }
-  const int nkt = cdiv(p.K, BK);
+  if (!nchw && p.g_KH * p.g_KW > MAX_TAPS)
+    return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: at most %d taps in the NHWC gather", MAX_TAPS);
+  // 32-bit element offsets inside the loaders
+  if ((double)p.M * p.a_ld > 2.0e9 && kind != KIND_WGRAD)
+    return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: operand A exceeds 2^31 elements");
   if (tile == 0) {
     // enough workgroups to fill 256 CUs (2 resident per CU) before growing the tile
     long t128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
@@ -492,16 +683,22 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     if (t128 >= 384) tile = 1;
     else if (t12864 >= 384 || (p.N <= 64 && p.M >= 4096)) tile = 2;
     else tile = 3;
-    if (nchw) tile = (kind == KIND_FWD) ? 2 : 3;
+    // few workgroups and a long contraction: 8 waves per workgroup (two per SIMD)
+    if (tile == 3 && kind != KIND_WGRAD && (long)cdiv(p.M, 64) * cdiv(p.N, 64) < 400 && p.K >= 512) tile = 5;
   }
-  int bm = (tile == 1 || tile == 2) ? 128 : 64;
-  int bn = (tile == 1 || tile == 4) ? 128 : 64;
+  if (tile == 5 && kind == KIND_WGRAD) tile = 3;
+  if (nchw) tile = (kind == KIND_FWD) ? 2 : 3;
+  const int bm = (tile == 1 || tile == 2) ? 128 : 64;
+  const int bn = (tile == 1 || tile == 4) ? 128 : 64;
+  const int bk = ((tile == 3 || tile == 5) && !nchw) ? 64 : 32;
+  const int nkt = cdiv(p.K, bk);
   if (p.splitk <= 0) {
     p.splitk = 1;
     if (kind == KIND_WGRAD) {
       long tiles = (long)cdiv(p.M, bm) * cdiv(p.N, bn);
       int want = (int)((512 + tiles - 1) / tiles);
-      int maxs = nkt / 4 > 0 ? nkt / 4 : 1;  // at least 4 K-tiles per split
+      int per = bk == 64 ? 2 : 4;                      // at least 128 rows of K per split
+      int maxs = nkt / per > 0 ? nkt / per : 1;
       p.splitk = want < maxs ? want : maxs;
       if (p.splitk < 1) p.splitk = 1;
       if (p.splitk > 1) p.c_atomic = 1;
@@ -511,23 +708,25 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
   p.splitk = cdiv(nkt, p.ktiles_per_split);
   if (p.splitk > 1 && !p.c_atomic)
     return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: split-K needs an accumulating epilogue");
-#define GO(BM_, BN_)                                                                   \
-  do {                                                                                 \
-    if (nchw) {                                                                        \
-      if (kind == KIND_FWD) return launch_cfg<128, 64, KIND_FWD, true>(p, stream);     \
-      if (kind == KIND_WGRAD) return launch_cfg<64, 64, KIND_WGRAD, true>(p, stream);  \
-      return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: no NCHW dgrad");                   \
-    }                                                                                  \
-    if (kind == KIND_FWD) return launch_cfg<BM_, BN_, KIND_FWD, false>(p, stream);     \
-    if (kind == KIND_DGRAD) return launch_cfg<BM_, BN_, KIND_DGRAD, false>(p, stream); \
-    return launch_cfg<BM_, BN_, KIND_WGRAD, false>(p, stream);                         \
+#define GO(BM_, BN_, BK_)                                                                   \
+  do {                                                                                      \
+    if (kind == KIND_FWD) return launch_cfg<BM_, BN_, BK_, KIND_FWD, false>(p, stream);     \
+    if (kind == KIND_DGRAD) return launch_cfg<BM_, BN_, BK_, KIND_DGRAD, false>(p, stream); \
+    return launch_cfg<BM_, BN_, BK_, KIND_WGRAD, false>(p, stream);                         \
   } while (0)
-  if (nchw) { GO(128, 64); }
+  if (nchw) {
+    if (kind == KIND_FWD) return launch_cfg<128, 64, 32, KIND_FWD, true>(p, stream);
+    if (kind == KIND_WGRAD) return launch_cfg<64, 64, 32, KIND_WGRAD, true>(p, stream);
+    return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: no NCHW dgrad");
+  }
   switch (tile) {
-    case 1: GO(128, 128);
-    case 2: GO(128, 64);
-    case 4: GO(64, 128);
-    default: GO(64, 64);
+    case 1: GO(128, 128, 32);
+    case 2: GO(128, 64, 32);
+    case 4: GO(64, 128, 32);
+    case 5:
+      if (kind == KIND_FWD) return launch_cfg<64, 64, 64, KIND_FWD, false, 2>(p, stream);
+      return launch_cfg<64, 64, 64, KIND_DGRAD, false, 2>(p, stream);
+    default: GO(64, 64, 64);
   }
 #undef GO
   return MMVQA_OK;

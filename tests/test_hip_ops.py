@@ -27,7 +27,8 @@ def act_cpu(name, x):
 # ----------------------------------------------------------------------------- linear (igemm FWD/DGRAD/WGRAD)
 @pytest.mark.parametrize("M,K,N,act,tile", [(70, 96, 50, "none", 0), (512, 768, 2304, "gelu", 0),
                                            (130, 64, 130, "serf", 1), (33, 100, 257, "relu", 2),
-                                           (200, 40, 64, "none", 3), (64, 256, 300, "none", 4)])
+                                           (200, 40, 64, "none", 3), (64, 256, 300, "none", 4),
+                                           (300, 1024, 130, "serf", 5), (100, 72, 64, "none", 5)])
 def test_linear_fwd(M, K, N, act, tile):
     torch.manual_seed(0)
     x, w, b, r = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K), torch.randn(N), torch.randn(M, N)
