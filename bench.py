@@ -131,6 +131,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    n_tuned = model.tune(img, ids, seg, mask)   # per-shape tile/split-K selection (untimed, like warm-up)
+    log(f"tuned {n_tuned} GEMM shapes")
     for i in range(a.warmup):
         step()
         torch.cuda.synchronize()

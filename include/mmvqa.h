@@ -230,6 +230,11 @@ int mmvqa_engine_forward(mmvqa_engine* e, mmvqa_stream_t s, const float* img, co
 /* accumulates into grads; dlogits same layout as logits; dfeat nullable */
 int mmvqa_engine_backward(mmvqa_engine* e, mmvqa_stream_t s, const float* dlogits, int dlogits_ld,
                           const float* dfeat);
+/* per-shape kernel configuration: while enabled, every implicit-GEMM shape met for the first time in
+ * forward/backward is timed over its candidate (tile, split-K) set and the fastest is kept for later
+ * calls.  A pass run with tuning enabled is a throw-away pass (outputs/statistics are garbage).
+ * Returns the number of tuned shapes so far (>= 0) or a negative error. */
+int mmvqa_engine_tune(mmvqa_engine* e, int enable);
 /* per-kernel-class timing (HIP events on the launch stream) of the NEXT forward+backward:
  * enable, run, then read back {n_launches, total_ms, algorithmic_flops} per class */
 int mmvqa_engine_profile(mmvqa_engine* e, int enable);

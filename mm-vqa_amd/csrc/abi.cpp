@@ -199,6 +199,11 @@ int mmvqa_engine_backward(mmvqa_engine* e, mmvqa_stream_t s, const float* dlogit
   if (!e || !dlogits) return mmvqa_set_error(MMVQA_ERR_ARG, "backward: null pointer");
   return engine_backward(e, ST(s), dlogits, dlogits_ld, dfeat);
 }
+int mmvqa_engine_tune(mmvqa_engine* e, int enable) {
+  if (!e) return mmvqa_set_error(MMVQA_ERR_ARG, "tune: null engine");
+  e->tuner.tuning = enable != 0;
+  return (int)e->tuner.table.size();
+}
 int mmvqa_engine_profile(mmvqa_engine* e, int enable) {
   if (!e) return mmvqa_set_error(MMVQA_ERR_ARG, "profile: null engine");
   e->prof_on = enable;

@@ -931,6 +931,7 @@ int engine_forward(mmvqa_engine* e, hipStream_t st, const float* img, const long
   e->img = img; e->ids = ids; e->seg = seg; e->mask = mask;
   e->logits = logits; e->logits_ld = logits_ld; e->feat = feat;
   e->training = training; e->seed = seed;
+  struct TunerScope { TunerScope(IgemmTuner* t) { mmvqa_set_tuner(t); } ~TunerScope() { mmvqa_set_tuner(nullptr); } } ts(&e->tuner);
   TRY(resnet_forward(e, st));
   const float pe = training ? d.p_emb_drop : 0.f;
   RUN(PROF_OTHER, 0,
@@ -947,6 +948,7 @@ int engine_forward(mmvqa_engine* e, hipStream_t st, const float* img, const long
 int engine_backward(mmvqa_engine* e, hipStream_t st, const float* dlogits, int dl_ld, const float* dfeat) {
   if (!e->planned || !e->bound || !e->img) return mmvqa_set_error(MMVQA_ERR_STATE, "engine_backward: run forward first");
   const mmvqa_model_desc& d = e->d;
+  struct TunerScope { TunerScope(IgemmTuner* t) { mmvqa_set_tuner(t); } ~TunerScope() { mmvqa_set_tuner(nullptr); } } ts(&e->tuner);
   const float* h = WS(e->enc_out_final);
   TRY(heads_backward(e, st, h, dlogits, dl_ld, dfeat));
   if (d.encoder == 0) TRY(bert_backward(e, st, WS(e->emb_out)));

@@ -109,6 +109,8 @@ struct mmvqa_engine {
   float* logits = nullptr;
   int logits_ld = 0;
   float* feat = nullptr;
+  // ---- per-shape kernel configuration
+  IgemmTuner tuner;
   // ---- profiling
   int prof_on = 0;
   struct ProfRec { hipEvent_t a, b; int cls; double flops; };

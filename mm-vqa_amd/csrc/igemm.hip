@@ -24,9 +24,11 @@
 // Prologues (BatchNorm apply + ReLU, BatchNorm backward) run at that LDS write; the epilogue fuses
 // bias / activation / dropout / residual / ReLU-mask / per-channel statistics so that BatchNorm never
 // needs its own pass over a feature map.
+#include <string>
 #include <type_traits>
+#include <vector>
 
-#include "common.h"
+#include "kernels.h"
 
 struct FastDiv {  // q = n / d for 0 <= n < 2^31 (host-computed magic; CUTLASS FastDivmod scheme)
   uint32_t mul, shr, d;
@@ -667,8 +669,72 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 (BK 64), 4 = 64x128, 5 = 64x64 with 8 waves (K-tile split in 2)
+// --------------------------------------------------------------------------- per-shape tuner
+// With tile == 0 the launcher consults the active tuner (set by the engine around forward/backward):
+// a shape seen for the first time while `tuning` is on is timed with HIP events for every candidate
+// (tile, split-K) using the caller's real operands, and the fastest is remembered.  Repeated launches
+// accumulate garbage into atomically-updated outputs, so a tuning pass is a throw-away pass (the Python
+// side restores the BatchNorm buffers and zeroes the gradients afterwards).
+static thread_local IgemmTuner* g_tuner = nullptr;
+void mmvqa_set_tuner(IgemmTuner* t) { g_tuner = t; }
+
+static std::string tune_key(const GemmParams& p, int kind, int nchw) {
+  char buf[160];
+  snprintf(buf, sizeof(buf), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", kind, nchw, p.M, p.N, p.K,
+           p.g_KH * p.g_KW, p.g_stride, p.g_Cs, p.a_pro, p.b_pro, p.epi_mode, p.act | (p.dact << 4),
+           (p.stat1 ? 1 : 0) | (p.stat2 ? 2 : 0) | (p.Mk ? 4 : 0) | (p.R ? 8 : 0) | (p.Cpre ? 16 : 0) |
+               (p.colsum ? 32 : 0) | (p.bias ? 64 : 0),
+           p.c_atomic, p.splitk);
+  return buf;
+}
+
+static int launch_one(GemmParams p, int kind, int nchw, int tile, hipStream_t stream);
+
 int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MMVQA_OK;
+  if (tile != 0 || nchw || !g_tuner) return launch_one(p, kind, nchw, tile, stream);
+  const std::string key = tune_key(p, kind, nchw);
+  auto it = g_tuner->table.find(key);
+  if (it == g_tuner->table.end()) {
+    if (!g_tuner->tuning) return launch_one(p, kind, nchw, 0, stream);
+    struct Cand { int tile, splitk; };
+    std::vector<Cand> cands;
+    const int tiles_f[] = {1, 2, 3, 5}, tiles_w[] = {1, 2, 3};
+    if (kind == KIND_WGRAD && p.splitk <= 0) {
+      for (int t : tiles_w) for (int sk : {0, 1, 2, 4, 8, 16}) cands.push_back({t, sk});
+    } else if (kind == KIND_WGRAD) {
+      for (int t : tiles_w) cands.push_back({t, p.splitk});
+    } else {
+      for (int t : tiles_f) cands.push_back({t, p.splitk});
+    }
+    hipEvent_t e0, e1;
+    HIP_CHECK_RET(hipEventCreate(&e0));
+    HIP_CHECK_RET(hipEventCreate(&e1));
+    float best = 1e30f;
+    Cand bc = cands[0];
+    for (const Cand& c : cands) {
+      GemmParams q = p;
+      q.splitk = c.splitk;
+      int r = launch_one(q, kind, nchw, c.tile, stream);  // warm-up (also sets the LDS attribute)
+      if (r != MMVQA_OK) continue;
+      HIP_CHECK_RET(hipEventRecord(e0, stream));
+      for (int i = 0; i < 3; ++i) launch_one(q, kind, nchw, c.tile, stream);
+      HIP_CHECK_RET(hipEventRecord(e1, stream));
+      HIP_CHECK_RET(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+      if (ms < best) { best = ms; bc = c; }
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    it = g_tuner->table.emplace(key, std::make_pair(bc.tile, bc.splitk)).first;
+  }
+  p.splitk = it->second.second;
+  return launch_one(p, kind, nchw, it->second.first, stream);
+}
+
+// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 (BK 64), 4 = 64x128, 5 = 64x64 with 8 waves (K-tile split in 2)
+static int launch_one(GemmParams p, int kind, int nchw, int tile, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MMVQA_OK;
   if (p.g_KH <= 0) { p.g_KH = p.g_KW = 1; p.g_stride = 1; p.g_pad = 0; }
   if (!nchw && p.g_KH * p.g_KW > MAX_TAPS)

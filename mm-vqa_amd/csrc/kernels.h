@@ -2,6 +2,16 @@
 #pragma once
 #include "common.h"
 
+#include <string>
+#include <unordered_map>
+#include <utility>
+
+// per-shape (tile, split-K) choices of the implicit-GEMM launcher; see igemm.hip
+struct IgemmTuner {
+  bool tuning = false;
+  std::unordered_map<std::string, std::pair<int, int>> table;
+};
+void mmvqa_set_tuner(IgemmTuner* t);
 int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t stream);
 int mmvqa_launch_attention(const AttnParams& p, int head_dim, int bwd, hipStream_t st);
 

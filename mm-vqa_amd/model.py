@@ -354,6 +354,30 @@ class Model(nn.Module):
             return out, 0, 0   # models/mmbert.py:167
         return out
 
+    # ------------------------------------------------------------------ per-shape kernel tuning
+    def tune(self, img, input_ids, segment_ids, input_mask):
+        """Time the candidate tile / split-K configurations of every GEMM shape of one training step
+        (forward + backward on the given batch) and keep the fastest.  Parameters, BatchNorm buffers
+        and gradients are left untouched (the pass itself computes garbage)."""
+        lib = L.lib()
+        bufs, nbt = self._flat[1].clone(), self._flat[2].clone()
+        was_training = self.training
+        self.train()
+        L.check(min(0, lib.mmvqa_engine_tune(self._handle, 1)))
+        try:
+            out = self._engine_forward(img, input_ids, segment_ids, input_mask)
+            logits = out[0] if isinstance(out, tuple) else out
+            feat = out[1] if isinstance(out, tuple) else None
+            self._engine_backward(torch.zeros_like(logits), None if feat is None else torch.zeros_like(feat))
+            torch.cuda.synchronize()
+        finally:
+            n = lib.mmvqa_engine_tune(self._handle, 0)
+            self._flat[1].copy_(bufs)
+            self._flat[2].copy_(nbt)
+            self._flat_grad.zero_()
+            self.train(was_training)
+        return n
+
     # ------------------------------------------------------------------ profiling (bench.py)
     def profile(self, enable: bool):
         L.check(L.lib().mmvqa_engine_profile(self._handle, 1 if enable else 0))
