@@ -524,110 +524,256 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
     }
   }
 
-  // ------------------------------------------------------------------ intra-workgroup K reduction
-  if constexpr (KS > 1) {
-    float* red = smem;   // the tile buffers are free after the loop's last barrier
+  // ------------------------------------------------------------------ epilogue
+  // The accumulator tiles go through LDS once (the tile buffers are free after the loop's last
+  // barrier) so that the output phase works on ROWS: every lane owns 4 consecutive columns, a wave
+  // stores/loads whole 256-512 B row segments with 16-byte accesses (the per-lane dword pattern of the
+  // MFMA layout reached only ~0.4 TB/s on the 616 MB tap maps), and every side tensor of the fused
+  // epilogue (residual, ReLU-mask source, BatchNorm inputs, saved pre-activations) is read the same way.
+  constexpr int LDC = BN + 4;
+  constexpr int CH = BN / 4;            // float4 chunks per tile row
+  constexpr int RP = NT / CH;           // rows per pass of the whole workgroup
+  constexpr int NPASS = BM / RP;
+  float* ctile = smem;
+  if (KS == 1 || ks == 0) {
+    static_for<TM * TN * 16>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int a = i / (TN * 16), b = (i / 16) % TN, e = i % 16;
+      ctile[(wm0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDC + wn0 + b * 32 + li] = acc[a][b][e];
+    });
+  }
+  __syncthreads();
+  if constexpr (KS > 1) {   // second K-group adds its partial tile (each element has exactly one owner lane)
     if (ks == 1) {
       static_for<TM * TN * 16>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        red[(wave * TM * TN * 16 + i) * 64 + lane] = acc[i / (TN * 16)][(i / 16) % TN][i % 16];
+        constexpr int a = i / (TN * 16), b = (i / 16) % TN, e = i % 16;
+        ctile[(wm0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * LDC + wn0 + b * 32 + li] += acc[a][b][e];
       });
     }
     __syncthreads();
-    if (ks != 0) return;
-    static_for<TM * TN * 16>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      acc[i / (TN * 16)][(i / 16) % TN][i % 16] += red[(wave * TM * TN * 16 + i) * 64 + lane];
-    });
   }
 
-  // ------------------------------------------------------------------ epilogue
-  const float inv_hw = p.tap_HW > 0 ? 1.0f / (float)p.tap_HW : 0.f;
-  const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.f;
-  const int slot = (blockIdx.y + blockIdx.x * 7 + blockIdx.z * 3) & (MMVQA_STAT_SLOTS - 1);
-  static_for<TN>([&](auto bI) {
-    constexpr int b = decltype(bI)::value;
-    const int col = n0 + wn0 + b * 32 + li;
-    const bool cvalid = col < p.N;
-    float bias = (p.bias && cvalid) ? p.bias[col] : 0.f;
-    float mks = 1.f, mkb = 0.f, mu1 = 0.f, is1 = 0.f, mu2 = 0.f, is2 = 0.f;
-    if (cvalid) {
-      if (p.Mk && p.mk_s) { mks = p.mk_s[col]; mkb = p.mk_b[col]; }
-      if (p.stat1 && p.stat_bwd) { mu1 = p.mean1[col]; is1 = p.invstd1[col]; }
-      if (p.stat2) { mu2 = p.mean2[col]; is2 = p.invstd2[col]; }
+  const int M = p.M, N = p.N;
+  const int c4 = tid % CH, rg = tid / CH;
+  const int col = n0 + c4 * 4;
+  const bool full = col + 3 < N;          // whole float4 inside the matrix
+  // side-tensor access helpers: 16-byte access when the chunk is complete, guarded scalars at a ragged edge
+  auto ldv = [&](const float* base, size_t off) __attribute__((always_inline)) {
+    f32x4 r = {0, 0, 0, 0};
+    if (full && !(off & 3)) r = ld4(base + off);
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (col + j < N) r[j] = base[off + j];
     }
-    double s_a = 0.0, s_b = 0.0, s_c = 0.0;
-    float cs = 0.f;
-    int tap_b = -1; float tap_acc = 0.f;
-    static_for<TM>([&](auto aI) {
-      constexpr int a = decltype(aI)::value;
-      static_for<16>([&](auto eI) {
-        constexpr int e = decltype(eI)::value;
-        const int row = m0 + wm0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (row >= p.M || !cvalid) return;
-        float v = acc[a][b][e] + bias;
-        if (p.Cpre) p.Cpre[(size_t)row * p.c_ld + col] = v;
-        if (p.epi_mode == EPI_TAP_FWD) {
-          int bi = row / p.tap_HW;
-          float w = act_fwd(p.act, v) * inv_hw;
-          if (bi != tap_b) {
-            if (tap_b >= 0) atomicAdd(&p.tap_out[(size_t)tap_b * p.N + col], tap_acc);
-            tap_b = bi; tap_acc = 0.f;
-          }
-          tap_acc += w;
-          return;
+    return r;
+  };
+  auto stv = [&](float* base, size_t off, f32x4 v) __attribute__((always_inline)) {
+    if (full && !(off & 3)) *reinterpret_cast<f32x4*>(base + off) = v;
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (col + j < N) base[off + j] = v[j];
+    }
+  };
+
+  if (p.c_atomic) {
+    // accumulate (weight gradients / split-K): one float per lane so that a wave-instruction adds to
+    // 256 contiguous bytes (MI355X_MICROARCH "Global float atomics": full rate only in that shape)
+    float* C = p.C;
+    const int ldc = p.c_ld;
+    for (int i = tid; i < BM * BN; i += NT) {
+      const int rl = i / BN, cl = i - rl * BN;
+      const int row = m0 + rl, cc = n0 + cl;
+      if (row < M && cc < N) atomicAdd(&C[(size_t)row * ldc + cc], ctile[rl * LDC + cl]);
+    }
+    return;
+  }
+
+  if (p.epi_mode == EPI_TAP_FWD) {
+    // v[img][col] += act(acc) / HW  (models/image_encoding.py:53-62: conv1x1 -> act -> global average pool).
+    // Row groups are first combined in LDS (per image slot), then one global atomic per (image, column).
+    constexpr int NIMG = 8;
+    const int act = p.act, HW = p.tap_HW;
+    const float inv_hw = 1.0f / (float)HW;
+    float* out = p.tap_out;
+    float* lacc = smem + BM * LDC;   // [NIMG][BN], behind the staged tile
+    const int img0 = m0 / HW;
+    for (int i = tid; i < NIMG * BN; i += NT) lacc[i] = 0.f;
+    __syncthreads();
+    int cur = -1;
+    f32x4 sum = {0, 0, 0, 0};
+    auto flush = [&]() __attribute__((always_inline)) {
+      if (cur < 0) return;
+      const int sl = cur - img0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (col + j >= N) continue;
+        if (sl < NIMG) atomicAdd(&lacc[sl * BN + c4 * 4 + j], sum[j]);
+        else atomicAdd(&out[(size_t)cur * N + col + j], sum[j]);
+      }
+    };
+#pragma unroll 1
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int rl = rg + ps * RP, row = m0 + rl;
+      if (row < M && col < N) {
+        const int img = row / HW;
+        if (img != cur) { flush(); cur = img; sum = f32x4{0, 0, 0, 0}; }
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[rl * LDC + c4 * 4]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum[j] += act_fwd(act, v[j]) * inv_hw;
+      }
+    }
+    flush();
+    __syncthreads();
+    for (int i = tid; i < NIMG * BN; i += NT) {
+      const int sl = i / BN, cl = i - sl * BN;
+      const float v = lacc[i];
+      if (v != 0.f && n0 + cl < N) atomicAdd(&out[(size_t)(img0 + sl) * N + n0 + cl], v);
+    }
+    return;
+  }
+
+  if (p.epi_mode == EPI_TAP_BWD) {
+    // du = dv[img] / HW * act'(u)
+    const int act = p.act, HW = p.tap_HW, ldc = p.c_ld;
+    const float inv_hw = 1.0f / (float)HW;
+    const float* dv = p.tap_dv;
+    float* C = p.C;
+#pragma unroll 1
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int rl = rg + ps * RP, row = m0 + rl;
+      if (row >= M || col >= N) break;
+      const int img = row / HW;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[rl * LDC + c4 * 4]);
+      const f32x4 g = ldv(dv, (size_t)img * N + col);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = g[j] * inv_hw * act_bwd(act, v[j]);
+      stv(C, (size_t)row * ldc + col, v);
+    }
+    return;
+  }
+
+  // general epilogue: +bias -> Cpre -> *act'(Pre) -> act -> dropout -> +R -> ReLU mask -> store -> statistics
+  {
+    float* C = p.C; const int ldc = p.c_ld;
+    float* Cpre = p.Cpre;
+    const float* Pre = p.Pre; const int dact = p.dact, pre_ld = p.pre_ld, act = p.act;
+    const float* R = p.R; const int r_ld = p.r_ld;
+    const float* Mk = p.Mk; const int mk_ld = p.mk_ld;
+    const float* Z1 = p.Z1; const float* Z2 = p.Z2; const int z1_ld = p.z1_ld, z2_ld = p.z2_ld;
+    double* st1 = p.stat1; double* st2 = p.stat2; const int stat_bwd = p.stat_bwd;
+    float* colsum = p.colsum;
+    const float drop_p = p.drop_p; const uint32_t drop_seed = p.drop_seed;
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+    const bool cok = col < N;
+    f32x4 bias = {0, 0, 0, 0}, mks = {1, 1, 1, 1}, mkb = {0, 0, 0, 0};
+    f32x4 mu1 = {0, 0, 0, 0}, is1 = {0, 0, 0, 0}, mu2 = {0, 0, 0, 0}, is2 = {0, 0, 0, 0};
+    if (cok) {
+      if (p.bias) bias = ldv(p.bias, col);
+      if (Mk && p.mk_s) { mks = ldv(p.mk_s, col); mkb = ldv(p.mk_b, col); }
+      if (st1 && stat_bwd) { mu1 = ldv(p.mean1, col); is1 = ldv(p.invstd1, col); }
+      if (st2) { mu2 = ldv(p.mean2, col); is2 = ldv(p.invstd2, col); }
+    }
+    double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0}, sc[4] = {0, 0, 0, 0};
+    f32x4 cs = {0, 0, 0, 0};
+#pragma unroll 1
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int rl = rg + ps * RP, row = m0 + rl;
+      if (row >= M || !cok) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[rl * LDC + c4 * 4]);
+      v += bias;
+      if (Cpre) stv(Cpre, (size_t)row * ldc + col, v);
+      if (dact) {
+        const f32x4 pr = ldv(Pre, (size_t)row * pre_ld + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= act_bwd(dact, pr[j]);
+      }
+      if (act) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_fwd(act, v[j]);
+      }
+      if (drop_p > 0.f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float u = rng_uniform(drop_seed, (uint32_t)row * (uint32_t)N + (uint32_t)(col + j));
+          v[j] = (u >= drop_p) ? v[j] * keep_scale : 0.f;
         }
-        if (p.epi_mode == EPI_TAP_BWD) {
-          int bi = row / p.tap_HW;
-          v = p.tap_dv[(size_t)bi * p.N + col] * inv_hw * act_bwd(p.act, v);
+      }
+      if (R) v += ldv(R, (size_t)row * r_ld + col);
+      if (Mk) {
+        const f32x4 m = ldv(Mk, (size_t)row * mk_ld + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (m[j] * mks[j] + mkb[j] > 0.f) ? v[j] : 0.f;
+      }
+      stv(C, (size_t)row * ldc + col, v);
+      if (st1) {
+        if (stat_bwd) {
+          const f32x4 z = ldv(Z1, (size_t)row * z1_ld + col);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { sa[j] += (double)v[j]; sb[j] += (double)(v[j] * ((z[j] - mu1[j]) * is1[j])); }
+          if (st2) {
+            const f32x4 z2 = ldv(Z2, (size_t)row * z2_ld + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[j] += (double)(v[j] * ((z2[j] - mu2[j]) * is2[j]));
+          }
         } else {
-          if (p.dact) v *= act_bwd(p.dact, p.Pre[(size_t)row * p.pre_ld + col]);
-          v = act_fwd(p.act, v);
-          if (p.drop_p > 0.f) {
-            float u = rng_uniform(p.drop_seed, (uint32_t)row * (uint32_t)p.N + (uint32_t)col);
-            v = (u >= p.drop_p) ? v * keep_scale : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { sa[j] += (double)v[j]; sb[j] += (double)v[j] * (double)v[j]; }
+        }
+      }
+      if (colsum) cs += v;
+    }
+    if (st1 || colsum) {
+      // reduce the RP row groups of the workgroup through LDS, then ONE atomic per column
+      __syncthreads();                       // everyone is done reading ctile
+      double* red = reinterpret_cast<double*>(smem);   // [RP][BN][3]
+      float* redf = smem;                               // [RP][BN] (colsum only)
+      if (st1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double* d = red + ((size_t)rg * BN + c4 * 4 + j) * 3;
+          d[0] = sa[j]; d[1] = sb[j]; d[2] = sc[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) redf[rg * BN + c4 * 4 + j] = cs[j];
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < N) {
+        if (st1) {
+          double a0 = 0, a1 = 0, a2 = 0;
+          for (int g = 0; g < RP; ++g) {
+            const double* d = red + ((size_t)g * BN + tid) * 3;
+            a0 += d[0]; a1 += d[1]; a2 += d[2];
           }
-          if (p.R) v += p.R[(size_t)row * p.r_ld + col];
-        }
-        if (p.Mk) {
-          float mval = p.Mk[(size_t)row * p.mk_ld + col] * mks + mkb;
-          if (!(mval > 0.f)) v = 0.f;
-        }
-        if (p.c_atomic) atomicAdd(&p.C[(size_t)row * p.c_ld + col], v);
-        else p.C[(size_t)row * p.c_ld + col] = v;
-        if (p.stat1) {
-          s_a += (double)v;
-          if (p.stat_bwd) {
-            s_b += (double)(v * ((p.Z1[(size_t)row * p.z1_ld + col] - mu1) * is1));
-            if (p.stat2) s_c += (double)(v * ((p.Z2[(size_t)row * p.z2_ld + col] - mu2) * is2));
-          } else {
-            s_b += (double)v * (double)v;
+          const int slot = (blockIdx.y + blockIdx.x * 7 + blockIdx.z * 3) & (MMVQA_STAT_SLOTS - 1);
+          double* d1 = st1 + ((size_t)slot * N + n0 + tid) * 2;
+          atomicAdd(d1, a0);
+          atomicAdd(d1 + 1, a1);
+          if (st2) {
+            double* d2 = st2 + ((size_t)slot * N + n0 + tid) * 2;
+            atomicAdd(d2, a0);
+            atomicAdd(d2 + 1, a2);
           }
+        } else {
+          float a0 = 0.f;
+          for (int g = 0; g < RP; ++g) a0 += redf[g * BN + tid];
+          atomicAdd(&colsum[n0 + tid], a0);
         }
-        if (p.colsum) cs += v;
-      });
-    });
-    if (p.epi_mode == EPI_TAP_FWD && tap_b >= 0) atomicAdd(&p.tap_out[(size_t)tap_b * p.N + col], tap_acc);
-    if (p.stat1) {
-      s_a += __shfl_xor(s_a, 32, 64);
-      s_b += __shfl_xor(s_b, 32, 64);
-      if (p.stat2) s_c += __shfl_xor(s_c, 32, 64);
-      if (lh == 0 && cvalid) {
-        double* d1 = p.stat1 + ((size_t)slot * p.N + col) * 2;
-        atomicAdd(d1, s_a);
-        atomicAdd(d1 + 1, s_b);
-        if (p.stat2) {
-          double* d2 = p.stat2 + ((size_t)slot * p.N + col) * 2;
-          atomicAdd(d2, s_a);
-          atomicAdd(d2 + 1, s_c);
+      }
+      if (st1 && colsum) {   // both requested (not used by the engine): second round for the float sums
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) redf[rg * BN + c4 * 4 + j] = cs[j];
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+          float a0 = 0.f;
+          for (int g = 0; g < RP; ++g) a0 += redf[g * BN + tid];
+          atomicAdd(&colsum[n0 + tid], a0);
         }
       }
     }
-    if (p.colsum) {
-      cs += __shfl_xor(cs, 32, 64);
-      if (lh == 0 && cvalid) atomicAdd(&p.colsum[col], cs);
-    }
-  });
+  }
 }
 
 // --------------------------------------------------------------------------- host launch
@@ -651,7 +797,9 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
   constexpr bool B_ROWK = (KIND == KIND_FWD);
   constexpr int A_TILE = A_ROWK ? BM * (BK + 4) : BK * (BM + 4);
   constexpr int B_TILE = B_ROWK ? BN * (BK + 4) : BK * (BN + 4);
-  constexpr size_t smem = (size_t)(2 * A_TILE + 2 * B_TILE + MAX_TAPS) * sizeof(float);
+  constexpr size_t tile_floats = (size_t)(2 * A_TILE + 2 * B_TILE + MAX_TAPS);
+  constexpr size_t epi_floats = (size_t)BM * (BN + 4) + 8 * BN;   // staged output tile + tap accumulators
+  constexpr size_t smem = (tile_floats > epi_floats ? tile_floats : epi_floats) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, KIND, NCHW, KS>,
