@@ -1,0 +1,292 @@
+"""Training loops (callers of the hot path) -- build-owned counterparts of the reference's scripts,
+which never ship to the GPU box (SURVEY.md 8(b) "Callers the build must supply"):
+
+  mlm      pretrain/roco_train.py:155-197 + pretrain/roco_utils.py:207-372 (train_one_epoch / validate)
+  supcon   pretrain/roco_supcon_train.py:137,168-202 + models/SupConLoss/supcon_utils.py:253-379
+  vqa      vqamed2019/train.py:125-296 + vqamed2019/utils.py:625-767
+
+Kept from the reference: option names and defaults, Adam(lr) + ReduceLROnPlateau(patience, factor) on the
+validation loss, zero_grad -> forward -> loss -> backward -> step order, loss / accuracy definitions,
+half-batch x 2 views for SupCon, best-val-loss checkpoint, the 5-epoch "recorder" dict
+{epoch, optimizer, scheduler, scaler, model}, --resume, the VQA early-stop counter and classifier[2] surgery.
+Not kept (out of scope): real datasets/tokenizer/augmentation (synthetic batches with the same
+layout stand in: mmvqa_amd.synth), wandb, BLEU.  One process per GPU under torch.distributed (RCCL).
+
+    python -m mmvqa_amd.train mlm    --run_name r --mlm_prob 0.15 --epochs 2 --steps_per_epoch 20
+    python -m mmvqa_amd.train supcon --run_name r --mlm_prob 0.15 --batch_size 32
+    python -m mmvqa_amd.train vqa    --run_name r --loss ASLSingleLabel --batch_size 64
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+from torch.optim import lr_scheduler
+
+from . import FusedAdam, Model, asl_loss, mlm_loss, split_feat, supcon_loss, synth
+from .ddp import GradReducer, all_gather_features
+
+
+def common_args(p):
+    p.add_argument("-r", "--run_name", type=str, default="run")
+    p.add_argument("--save_dir", type=str, default="save")
+    p.add_argument("--batch_size", type=int, default=16)
+    p.add_argument("--patience", type=int, default=5)
+    p.add_argument("--factor", type=float, default=0.1)
+    p.add_argument("--epochs", type=int, default=10)
+    p.add_argument("--steps_per_epoch", type=int, default=50, help="synthetic batches per epoch")
+    p.add_argument("--val_steps", type=int, default=5)
+    p.add_argument("--n_layers", type=int, default=4)
+    p.add_argument("--heads", type=int, default=12)
+    p.add_argument("--type_vocab_size", type=int, default=2)
+    p.add_argument("--vocab_size", type=int, default=30522)
+    p.add_argument("--hidden_size", type=int, default=768)
+    p.add_argument("--hidden_dropout_prob", type=float, default=0.3)
+    p.add_argument("--cnn_encoder", type=str, default="resnet152")
+    p.add_argument("--transformer_model", type=str, default="transformer",
+                   choices=["transformer", "realformer", "feedback-transformer"])
+    p.add_argument("--num_vis", type=int, default=5)
+    p.add_argument("--use_relu", action="store_true", default=False)
+    p.add_argument("--resume", action="store_true", default=False)
+    p.add_argument("--image_size", type=int, default=224)
+    p.add_argument("--seed", type=int, default=1234)
+    p.add_argument("--state_dict", type=str, default=None, help="local checkpoint to start from")
+    # reduced backbones for smoke tests
+    p.add_argument("--resnet_layers", type=int, nargs=4, default=[3, 8, 36, 3])
+    p.add_argument("--resnet_width", type=int, default=64)
+    p.add_argument("--emb_vocab", type=int, default=30522)
+
+
+class Ctx:
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        self.dev = torch.device("cuda", local if self.world > 1 else 0)
+        torch.cuda.set_device(self.dev)
+
+    def mean(self, x: float) -> float:
+        if self.world == 1:
+            return x
+        t = torch.tensor([x], device=self.dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t) / self.world
+
+
+def build(args, ctx, n_classes=None):
+    torch.manual_seed(args.seed)          # identical replicas
+    model = Model(args)
+    if args.state_dict:
+        sd = torch.load(args.state_dict, map_location="cpu")
+        own = model.state_dict()
+        model.load_state_dict({k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}, strict=False)
+    if n_classes is not None:              # vqamed2019/train.py:137,141,149
+        model.classifier[2] = torch.nn.Linear(args.hidden_size, n_classes)
+    model.to(ctx.dev)
+    model.set_seed(args.seed + ctx.rank)
+    opt = FusedAdam(model, lr=args.lr)
+    sched = lr_scheduler.ReduceLROnPlateau(_SchedShim(opt), patience=args.patience, factor=args.factor)
+    return model, opt, sched, GradReducer(model.flat_grads)
+
+
+class _SchedShim(torch.optim.Optimizer):
+    """lets torch's ReduceLROnPlateau drive FusedAdam.param_groups[0]['lr']"""
+
+    def __init__(self, fused):
+        self.fused = fused
+        self.param_groups = fused.param_groups
+        self.defaults = {}
+        self.state = {}
+
+
+def save_recorder(args, epoch, model, opt, sched):
+    os.makedirs(args.save_dir, exist_ok=True)
+    torch.save({"epoch": epoch, "optimizer": opt.state_dict(), "scheduler": sched.state_dict(), "scaler": {},
+                "model": model.state_dict()}, os.path.join(args.save_dir, "recorder_2.pt"))
+
+
+def maybe_resume(args, model, opt, sched):
+    path = os.path.join(args.save_dir, "recorder_2.pt")
+    if not (args.resume and os.path.exists(path)):
+        return 0
+    rec = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(rec["model"])
+    opt.load_state_dict(rec["optimizer"])
+    sched.load_state_dict(rec["scheduler"])
+    return rec["epoch"] + 1
+
+
+# ----------------------------------------------------------------------------------------- MLM
+def run_mlm(args):
+    ctx = Ctx(args)
+    args.dataset, args.task = "roco", "MLM"
+    model, opt, sched, red = build(args, ctx)
+    T, B, V = args.max_position_embeddings, args.batch_size, args.vocab_size
+    best, start = float("inf"), maybe_resume(args, model, opt, sched)
+    for epoch in range(start, args.epochs):
+        model.train()
+        tl, nm, nc = 0.0, 0.0, 0.0
+        for i in range(args.steps_per_epoch):
+            img, ids, seg, mask, tgt = synth.roco_batch(B, T, args.image_size, min(V, args.emb_vocab),
+                                                        seed=args.seed + 7919 * (epoch * 100003 + i) + ctx.rank,
+                                                        device=ctx.dev, mlm_prob=args.mlm_prob)
+            opt.zero_grad()
+            loss, pred, stats = mlm_loss(model(img, ids, seg, mask), tgt)
+            loss.backward()
+            red.allreduce()
+            opt.step(grad_scale=1.0 / ctx.world, zero_grad=True)
+            s = stats.tolist()               # per-step host sync, as roco_utils.py:267
+            tl, nm, nc = tl + s[0], nm + s[1], nc + s[2]
+        vl, va = validate_mlm(args, ctx, model, epoch)
+        sched.step(vl)
+        if (epoch + 1) % 5 == 0 and ctx.rank == 0:
+            save_recorder(args, epoch, model, opt, sched)
+        tl = ctx.mean(tl / args.steps_per_epoch)
+        if ctx.rank == 0:
+            print(f"Epoch {epoch + 1}/{args.epochs} Learning rate: {opt.param_groups[0]['lr']:.7f}, Train loss: {tl:.4f}, "
+                  f"Train acc: {100.0 * nc / max(nm, 1):.4f} ,Val loss: {vl:.4f}, Val acc: {va:.4f}", flush=True)
+            if vl < best:
+                os.makedirs(os.path.join(args.save_dir, args.task), exist_ok=True)
+                torch.save(model.state_dict(), os.path.join(args.save_dir, args.task, args.run_name + ".pt"))
+        best = min(best, vl)
+    return best
+
+
+@torch.no_grad()
+def validate_mlm(args, ctx, model, epoch):
+    model.eval()
+    vl, nm, nc = 0.0, 0.0, 0.0
+    for i in range(args.val_steps):
+        img, ids, seg, mask, tgt = synth.roco_batch(args.batch_size, args.max_position_embeddings, args.image_size,
+                                                    min(args.vocab_size, args.emb_vocab), seed=10 ** 6 + i + ctx.rank,
+                                                    device=ctx.dev, mlm_prob=args.mlm_prob)
+        out = model(img, ids, seg, mask)
+        logits = out[0] if isinstance(out, tuple) else out
+        _, _, stats = mlm_loss(logits, tgt)
+        s = stats.tolist()
+        vl, nm, nc = vl + s[0], nm + s[1], nc + s[2]
+    return ctx.mean(vl / args.val_steps), 100.0 * nc / max(nm, 1)
+
+
+# ----------------------------------------------------------------------------------------- MLM + SupCon
+def run_supcon(args):
+    ctx = Ctx(args)
+    args.dataset, args.task, args.supcon = "roco", "MLM", True
+    model, opt, sched, red = build(args, ctx)
+    T, V = args.max_position_embeddings, args.vocab_size
+    n = args.batch_size // 2                      # roco_supcon_train.py:137: the loader yields bs//2 pairs
+    best, start = float("inf"), maybe_resume(args, model, opt, sched)
+    for epoch in range(start, args.epochs):
+        model.train()
+        tl = 0.0
+        for i in range(args.steps_per_epoch):
+            sd = args.seed + 7919 * (epoch * 100003 + i) + ctx.rank
+            a = synth.roco_batch(n, T, args.image_size, min(V, args.emb_vocab), seed=sd, device=ctx.dev, mlm_prob=args.mlm_prob)
+            b = synth.roco_batch(n, T, args.image_size, min(V, args.emb_vocab), seed=sd + 1, device=ctx.dev, mlm_prob=args.mlm_prob)
+            # process_tensors (supcon_utils.py:253-256): views concatenated along the batch; segment ids / mask of view 1
+            img, ids, tgt = (torch.cat([x, y], 0) for x, y in ((a[0], b[0]), (a[1], b[1]), (a[4], b[4])))
+            seg, mask = torch.cat([a[2], a[2]], 0), torch.cat([a[3], a[3]], 0)
+            opt.zero_grad()
+            logits, feat = model(img, ids, seg, mask)
+            loss = mlm_loss(logits, tgt)[0]
+            f = all_gather_features(feat)          # global negatives under DDP
+            w = ctx.world
+            parts = f.view(w, 2, n, -1)
+            feats = torch.cat([parts[:, 0].reshape(w * n, 1, -1), parts[:, 1].reshape(w * n, 1, -1)], 1)
+            loss = loss + supcon_loss(feats.contiguous())
+            loss.backward()
+            red.allreduce()
+            opt.step(grad_scale=1.0 / ctx.world, zero_grad=True)
+            tl += float(loss.detach())
+        vl, va = validate_mlm(args, ctx, model, epoch)
+        sched.step(vl)
+        if ctx.rank == 0:
+            print(f"Epoch {epoch + 1}/{args.epochs} Learning rate: {opt.param_groups[0]['lr']:.7f}, "
+                  f"Train loss: {tl / args.steps_per_epoch:.4f}, Val loss: {vl:.4f}, Val acc: {va:.4f}", flush=True)
+        best = min(best, vl)
+    return best
+
+
+# ----------------------------------------------------------------------------------------- VQA-Med-2019
+def run_vqa(args):
+    ctx = Ctx(args)
+    args.dataset, args.task = "VQA-Med", "MLM"
+    C = args.num_classes
+    model, opt, sched, red = build(args, ctx, n_classes=C)
+    T, B = args.max_position_embeddings, args.batch_size
+    crit = (lambda lg, t: asl_loss(lg, t)) if args.loss == "ASLSingleLabel" else (lambda lg, t: mlm_loss(lg, t)[0])
+    best_loss, best_acc1, best_acc2, counter = float("inf"), 0.0, 0.0, 0
+    for epoch in range(args.epochs):
+        model.train()
+        tl = 0.0
+        for i in range(args.steps_per_epoch):
+            img, ids, seg, mask, tgt = synth.vqa_batch(B, T, args.image_size, args.emb_vocab, C,
+                                                       seed=args.seed + 7919 * (epoch * 100003 + i) + ctx.rank, device=ctx.dev)
+            opt.zero_grad()
+            logits, _, _ = model(img, ids, seg, mask)       # utils.py:646
+            loss = crit(logits, tgt)
+            loss.backward()
+            red.allreduce()
+            opt.step(grad_scale=1.0 / ctx.world, zero_grad=True)
+            tl += float(loss.detach())
+        model.eval()
+        vl, correct, total = 0.0, 0, 0
+        with torch.no_grad():
+            for i in range(args.val_steps):
+                img, ids, seg, mask, tgt = synth.vqa_batch(B, T, args.image_size, args.emb_vocab, C, seed=10 ** 6 + i, device=ctx.dev)
+                logits, _, _ = model(img, ids, seg, mask)
+                vl += float(crit(logits, tgt))
+                correct += int((logits.softmax(1).argmax(1) == tgt).sum())   # utils.py:673
+                total += B
+        vl, acc = ctx.mean(vl / args.val_steps), 100.0 * correct / total
+        sched.step(vl)
+        if ctx.rank == 0:
+            print(f"Epoch {epoch + 1}/{args.epochs} lr {opt.param_groups[0]['lr']:.7f} train_loss {tl / args.steps_per_epoch:.4f} "
+                  f"val_loss {vl:.4f} val_total_acc {acc:.2f}", flush=True)
+        best_loss = min(best_loss, vl)
+        best_acc1 = max(best_acc1, acc)
+        if best_acc1 > best_acc2:                # train.py:288-296 early stop
+            counter, best_acc2 = 0, best_acc1
+        else:
+            counter += 1
+            if counter > args.counter:
+                if ctx.rank == 0:
+                    print("Counter expired, finishing.")
+                break
+    return best_loss
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    mode = argv.pop(0) if argv and argv[0] in ("mlm", "supcon", "vqa") else "mlm"
+    p = argparse.ArgumentParser(description=f"mmvqa_amd training ({mode})")
+    common_args(p)
+    if mode in ("mlm", "supcon"):
+        p.add_argument("--mlm_prob", type=float, default=0.15)
+        p.add_argument("--lr", type=float, default=2e-5)
+        p.add_argument("--max_position_embeddings", type=int, default=75)
+        if mode == "supcon":
+            p.add_argument("--con_task", type=str, default="supcon", choices=["simclr", "supcon"])
+            p.add_argument("--similarity", type=str, default="sentence_transformers")
+    else:
+        p.add_argument("--lr", type=float, default=1e-4)
+        p.add_argument("--max_position_embeddings", type=int, default=28)
+        p.add_argument("--loss", type=str, default="CrossEntropyLoss", choices=["CrossEntropyLoss", "ASLSingleLabel"])
+        p.add_argument("--num_classes", type=int, default=1552)
+        p.add_argument("--counter", type=int, default=20)
+    args = p.parse_args(argv)
+    out = {"mlm": run_mlm, "supcon": run_supcon, "vqa": run_vqa}[mode](args)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()
