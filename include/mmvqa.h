@@ -27,6 +27,8 @@ typedef void* mmvqa_stream_t; /* hipStream_t */
 #define MMVQA_ACT_RELU 1
 #define MMVQA_ACT_GELU 2 /* models/transformer.py:7-8 */
 #define MMVQA_ACT_SERF 3 /* models/serf.py:23-24 */
+#define MMVQA_ACT_SILU 4 /* timm tf_efficientnetv2_m activations */
+#define MMVQA_ACT_SIGMOID 5 /* squeeze-excite gate */
 
 #define MMVQA_KIND_FWD 0   /* C[pix,co]      = sum X[pix@tap,ci] W[co,tap,ci]      */
 #define MMVQA_KIND_DGRAD 1 /* C[pix_in,ci]   = sum dZ[pix_out,co] W[co,tap,ci]     */
@@ -89,6 +91,9 @@ typedef struct mmvqa_gemm_desc {
   const float* mean2;
   const float* invstd2;
   float* colsum;
+  const float* gate; /* PRO_SILU_GATE: [image][g_Cs] squeeze-excite gates; image = pixel / gate_hw */
+  int gate_hw;
+  int mk_mode;       /* 0: ReLU mask (Mk*s+b > 0), 1: multiply by SiLU'(Mk*s+b) */
 } mmvqa_gemm_desc;
 
 /* Fused attention (models/transformer.py:19-30 and models/realformer.py:30-45). */

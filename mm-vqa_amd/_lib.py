@@ -15,9 +15,9 @@ LIB_PATH = os.path.join(_HERE, "libmmvqa_hip.so")
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 c_ptr = C.c_void_p
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_SERF = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SERF, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 KIND_FWD, KIND_DGRAD, KIND_WGRAD = 0, 1, 2
-PRO_NONE, PRO_AFFINE_RELU, PRO_DZ, PRO_AFFINE = 0, 1, 2, 3
+PRO_NONE, PRO_AFFINE_RELU, PRO_DZ, PRO_AFFINE, PRO_AFFINE_SILU, PRO_SILU_GATE = 0, 1, 2, 3, 4, 5
 EPI_PLAIN, EPI_TAP_FWD, EPI_TAP_BWD = 0, 1, 2
 STAT_SLOTS = 16
 
@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
         ("stat1", c_ptr), ("stat_bwd", C.c_int), ("Z1", c_ptr), ("z1_ld", C.c_int), ("mean1", c_ptr),
         ("invstd1", c_ptr),
         ("stat2", c_ptr), ("Z2", c_ptr), ("z2_ld", C.c_int), ("mean2", c_ptr), ("invstd2", c_ptr),
-        ("colsum", c_ptr),
+        ("colsum", c_ptr), ("gate", c_ptr), ("gate_hw", C.c_int), ("mk_mode", C.c_int),
     ]
 
 

@@ -8,9 +8,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SERF = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SERF = 3, ACT_SILU = 4, ACT_SIGMOID = 5 };
 // A/B operand prologues (applied when a tile is written to LDS)
-enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_DZ = 2, PRO_AFFINE = 3 };
+enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_DZ = 2, PRO_AFFINE = 3, PRO_AFFINE_SILU = 4, PRO_SILU_GATE = 5 };
 // epilogue special modes
 enum { EPI_PLAIN = 0, EPI_TAP_FWD = 1, EPI_TAP_BWD = 2 };
 // contraction kinds of the implicit-GEMM family (MMVQA_KIND_* in the ABI)
@@ -57,8 +57,14 @@ __device__ __forceinline__ void serf_parts(float x, float& e, float& sp) {
   sp = e < 0.01f ? e * (1.0f - e * (0.5f - e * 0.33333333333f)) : __logf(1.0f + e);
 }
 
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+__device__ __forceinline__ float dsilu_f(float x) { const float s = sigmoid_f(x); return s * (1.0f + x * (1.0f - s)); }
+
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
+    case ACT_SILU: return silu_f(x);
+    case ACT_SIGMOID: return sigmoid_f(x);
     case ACT_RELU: return x > 0.f ? x : 0.f;
     case ACT_GELU: return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
     case ACT_SERF: {
@@ -72,6 +78,8 @@ __device__ __forceinline__ float act_fwd(int act, float x) {
 
 __device__ __forceinline__ float act_bwd(int act, float x) {
   switch (act) {
+    case ACT_SILU: return dsilu_f(x);
+    case ACT_SIGMOID: { const float s = sigmoid_f(x); return s * (1.0f - s); }
     case ACT_RELU: return x > 0.f ? 1.f : 0.f;
     case ACT_GELU: {
       float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));

@@ -942,3 +942,372 @@ int k_dropout_copy(hipStream_t st, const float* x, float* y, long n, float p, ui
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }
+
+// =========================================================================== EfficientNetV2 pieces
+// (timm tf_efficientnetv2_m as the reference instantiates it, models/image_encoding.py:15,26,100-115)
+
+// out = post( pre(z*s+b) + idn' ), idn' = idn | iact(idn*is+ib) | nothing
+__global__ void bn_act_add_kernel(const float* __restrict__ z, const float* __restrict__ s,
+                                  const float* __restrict__ b, int pre_act, const float* __restrict__ idn,
+                                  const float* __restrict__ ids, const float* __restrict__ idb, int idn_act,
+                                  int post_act, float* __restrict__ out, long n4, int C4) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    int c = (int)(i % C4) * 4;
+    f32x4 zv = reinterpret_cast<const f32x4*>(z)[i];
+    f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = act_fwd(pre_act, zv[j] * sv[j] + bv[j]);
+    if (idn) {
+      f32x4 iv = reinterpret_cast<const f32x4*>(idn)[i];
+      if (ids) {
+        f32x4 s2 = *reinterpret_cast<const f32x4*>(ids + c), b2 = *reinterpret_cast<const f32x4*>(idb + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) iv[j] = act_fwd(idn_act, iv[j] * s2[j] + b2[j]);
+      }
+      o += iv;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = act_fwd(post_act, o[j]);
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
+// Depthwise 3x3 (groups = C), NHWC.  Workgroup = 32 pixel lanes x 8 channel quads (32 channels):
+// the per-channel statistics are reduced over the 32 pixel lanes in LDS, then one atomic per channel.
+//   forward : z2 = dw(silu(z1*s1+b1)) ; statistics of z2
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ z1, const float* __restrict__ s1,
+                                                        const float* __restrict__ b1, const float* __restrict__ w,
+                                                        float* __restrict__ z2, double* __restrict__ stat, int N,
+                                                        int H, int W, int C, int OH, int OW, int stride, int pad) {
+  __shared__ double red[256 * 8];
+  const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c = blockIdx.y * 32 + q * 4;
+  const long npix = (long)N * OH * OW;
+  f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
+  f32x4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[t][j] = w[(size_t)(c + j) * 9 + t];
+  double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+  for (long pix = (long)blockIdx.x * 32 + pl; pix < npix; pix += (long)gridDim.x * 32) {
+    int ox = (int)(pix % OW); long t = pix / OW;
+    int oy = (int)(t % OH), n = (int)(t / OH);
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      int y = oy * stride - pad + kh;
+      if (y < 0 || y >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        int x = ox * stride - pad + kw;
+        if (x < 0 || x >= W) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(z1 + ((size_t)(n * H + y) * W + x) * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += silu_f(v[j] * sv[j] + bv[j]) * wv[kh * 3 + kw][j];
+      }
+    }
+    *reinterpret_cast<f32x4*>(z2 + (size_t)pix * C + c) = acc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sa[j] += (double)acc[j]; sb[j] += (double)acc[j] * (double)acc[j]; }
+  }
+  if (stat) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[threadIdx.x * 8 + j] = sa[j]; red[threadIdx.x * 8 + 4 + j] = sb[j]; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int qq = threadIdx.x >> 2, j = threadIdx.x & 3;
+      double a0 = 0, a1 = 0;
+      for (int r = 0; r < 32; ++r) { a0 += red[(r * 8 + qq) * 8 + j]; a1 += red[(r * 8 + qq) * 8 + 4 + j]; }
+      const int slot = blockIdx.x & (MMVQA_STAT_SLOTS - 1);
+      double* d = stat + ((size_t)slot * C + blockIdx.y * 32 + qq * 4 + j) * 2;
+      atomicAdd(d, a0);
+      atomicAdd(d + 1, a1);
+    }
+  }
+}
+
+//   backward (data): da1 = dw^T(dz2), dz2 = P*g + Q*z2 + R ; du1 = da1 * silu'(z1*s1+b1) -> g1 ; BN1-backward sums
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(
+    const float* __restrict__ g2, const float* __restrict__ z2, const float* __restrict__ P, const float* __restrict__ Q,
+    const float* __restrict__ R, const float* __restrict__ w, const float* __restrict__ z1, const float* __restrict__ s1,
+    const float* __restrict__ b1, const float* __restrict__ mean1, const float* __restrict__ invstd1,
+    float* __restrict__ g1, double* __restrict__ stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad) {
+  __shared__ double red[256 * 8];
+  const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c = blockIdx.y * 32 + q * 4;
+  const long npix = (long)N * H * W;
+  f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
+  f32x4 mu = *reinterpret_cast<const f32x4*>(mean1 + c), is = *reinterpret_cast<const f32x4*>(invstd1 + c);
+  f32x4 Pv = *reinterpret_cast<const f32x4*>(P + c), Qv = *reinterpret_cast<const f32x4*>(Q + c),
+        Rv = *reinterpret_cast<const f32x4*>(R + c);
+  f32x4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[t][j] = w[(size_t)(c + j) * 9 + t];
+  double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+  for (long pix = (long)blockIdx.x * 32 + pl; pix < npix; pix += (long)gridDim.x * 32) {
+    int x = (int)(pix % W); long t = pix / W;
+    int y = (int)(t % H), n = (int)(t / H);
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      int ty = y + pad - kh;
+      if (ty < 0 || ty % stride) continue;
+      int oy = ty / stride;
+      if (oy >= OH) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        int tx = x + pad - kw;
+        if (tx < 0 || tx % stride) continue;
+        int ox = tx / stride;
+        if (ox >= OW) continue;
+        size_t o = ((size_t)(n * OH + oy) * OW + ox) * C + c;
+        f32x4 gv = *reinterpret_cast<const f32x4*>(g2 + o), zv = *reinterpret_cast<const f32x4*>(z2 + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += (gv[j] * Pv[j] + zv[j] * Qv[j] + Rv[j]) * wv[kh * 3 + kw][j];
+      }
+    }
+    f32x4 z = *reinterpret_cast<const f32x4*>(z1 + (size_t)pix * C + c), o4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o4[j] = acc[j] * dsilu_f(z[j] * sv[j] + bv[j]);
+      sa[j] += (double)o4[j];
+      sb[j] += (double)(o4[j] * ((z[j] - mu[j]) * is[j]));
+    }
+    *reinterpret_cast<f32x4*>(g1 + (size_t)pix * C + c) = o4;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[threadIdx.x * 8 + j] = sa[j]; red[threadIdx.x * 8 + 4 + j] = sb[j]; }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int qq = threadIdx.x >> 2, j = threadIdx.x & 3;
+    double a0 = 0, a1 = 0;
+    for (int r = 0; r < 32; ++r) { a0 += red[(r * 8 + qq) * 8 + j]; a1 += red[(r * 8 + qq) * 8 + 4 + j]; }
+    const int slot = blockIdx.x & (MMVQA_STAT_SLOTS - 1);
+    double* d = stat + ((size_t)slot * C + blockIdx.y * 32 + qq * 4 + j) * 2;
+    atomicAdd(d, a0);
+    atomicAdd(d + 1, a1);
+  }
+}
+
+//   backward (weight): dW[c][tap] += sum_pix dz2[pix,c] * silu(z1*s1+b1)[pix@tap, c]
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
+    const float* __restrict__ g2, const float* __restrict__ z2, const float* __restrict__ P, const float* __restrict__ Q,
+    const float* __restrict__ R, const float* __restrict__ z1, const float* __restrict__ s1, const float* __restrict__ b1,
+    float* __restrict__ dw, int N, int H, int W, int C, int OH, int OW, int stride, int pad) {
+  __shared__ float red[32 * 8 * 36];
+  const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c = blockIdx.y * 32 + q * 4;
+  const long npix = (long)N * OH * OW;
+  f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
+  f32x4 Pv = *reinterpret_cast<const f32x4*>(P + c), Qv = *reinterpret_cast<const f32x4*>(Q + c),
+        Rv = *reinterpret_cast<const f32x4*>(R + c);
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0, 0, 0, 0};
+  for (long pix = (long)blockIdx.x * 32 + pl; pix < npix; pix += (long)gridDim.x * 32) {
+    int ox = (int)(pix % OW); long t = pix / OW;
+    int oy = (int)(t % OH), n = (int)(t / OH);
+    f32x4 gv = *reinterpret_cast<const f32x4*>(g2 + (size_t)pix * C + c), zv = *reinterpret_cast<const f32x4*>(z2 + (size_t)pix * C + c), dz;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dz[j] = gv[j] * Pv[j] + zv[j] * Qv[j] + Rv[j];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      int y = oy * stride - pad + kh;
+      if (y < 0 || y >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        int x = ox * stride - pad + kw;
+        if (x < 0 || x >= W) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(z1 + ((size_t)(n * H + y) * W + x) * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[kh * 3 + kw][j] += dz[j] * silu_f(v[j] * sv[j] + bv[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(pl * 8 + q) * 36 + j * 9 + t] = acc[t][j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * 36; i += 256) {   // (quad, channel-in-quad * 9 + tap)
+    const int qq = i / 36, e = i - qq * 36;
+    float a0 = 0.f;
+    for (int r = 0; r < 32; ++r) a0 += red[(r * 8 + qq) * 36 + e];
+    atomicAdd(&dw[(size_t)(blockIdx.y * 32 + qq * 4) * 9 + e], a0);
+  }
+}
+
+// squeeze: pool[n][c] = mean_hw silu(z*s+b)
+__global__ void se_pool_kernel(const float* __restrict__ z, const float* __restrict__ s, const float* __restrict__ b,
+                               float* __restrict__ pool, int HW, int C) {
+  const int n = blockIdx.y, c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= C) return;
+  f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c), acc = {0, 0, 0, 0};
+  for (int p = 0; p < HW; ++p) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(z + ((size_t)n * HW + p) * C + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += silu_f(v[j] * sv[j] + bv[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] /= (float)HW;
+  *reinterpret_cast<f32x4*>(pool + (size_t)n * C + c) = acc;
+}
+
+// dgate[n][c] = sum_hw t[pix,c] * silu(z*s+b)[pix,c]   (t = gradient wrt the gated activation)
+__global__ void se_dgate_kernel(const float* __restrict__ t, const float* __restrict__ z, const float* __restrict__ s,
+                                const float* __restrict__ b, float* __restrict__ dgate, int HW, int C) {
+  const int n = blockIdx.y, c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= C) return;
+  f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c), acc = {0, 0, 0, 0};
+  for (int p = 0; p < HW; ++p) {
+    size_t o = ((size_t)n * HW + p) * C + c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(z + o), tv = *reinterpret_cast<const f32x4*>(t + o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += tv[j] * silu_f(v[j] * sv[j] + bv[j]);
+  }
+  *reinterpret_cast<f32x4*>(dgate + (size_t)n * C + c) = acc;
+}
+
+// du = (t * gate[n][c] + add[n][c] / HW) * act'(z*s+b) -> out ; BatchNorm-backward sums of bn(z)
+// (gate / add nullable).  Same workgroup shape as the depthwise kernels.
+__global__ __launch_bounds__(256) void act_bwd_stats_kernel(
+    const float* __restrict__ t, const float* __restrict__ gate, const float* __restrict__ add,
+    const float* __restrict__ z, const float* __restrict__ s, const float* __restrict__ b,
+    const float* __restrict__ mean, const float* __restrict__ invstd, int act, float* __restrict__ out,
+    double* __restrict__ stat, long npix, int HW, int C) {
+  __shared__ double red[256 * 8];
+  const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c = blockIdx.y * 32 + q * 4;
+  const bool cv = c < C;              // C is a multiple of 4, not necessarily of 32 (24-channel stem/stage 0)
+  const int cc = cv ? c : 0;
+  f32x4 sv = *reinterpret_cast<const f32x4*>(s + cc), bv = *reinterpret_cast<const f32x4*>(b + cc);
+  f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cc), is = *reinterpret_cast<const f32x4*>(invstd + cc);
+  const float inv_hw = 1.0f / (float)HW;
+  double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+  if (cv) {
+    for (long pix = (long)blockIdx.x * 32 + pl; pix < npix; pix += (long)gridDim.x * 32) {
+      const long n = pix / HW;
+      f32x4 tv = *reinterpret_cast<const f32x4*>(t + (size_t)pix * C + c);
+      f32x4 zv = *reinterpret_cast<const f32x4*>(z + (size_t)pix * C + c), o;
+      if (gate) {
+        f32x4 gv = *reinterpret_cast<const f32x4*>(gate + (size_t)n * C + c), av = *reinterpret_cast<const f32x4*>(add + (size_t)n * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tv[j] = tv[j] * gv[j] + av[j] * inv_hw;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = tv[j] * act_bwd(act, zv[j] * sv[j] + bv[j]);
+        sa[j] += (double)o[j];
+        sb[j] += (double)(o[j] * ((zv[j] - mu[j]) * is[j]));
+      }
+      *reinterpret_cast<f32x4*>(out + (size_t)pix * C + c) = o;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[threadIdx.x * 8 + j] = sa[j]; red[threadIdx.x * 8 + 4 + j] = sb[j]; }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int qq = threadIdx.x >> 2, j = threadIdx.x & 3;
+    const int ch = blockIdx.y * 32 + qq * 4 + j;
+    if (ch < C) {
+      double a0 = 0, a1 = 0;
+      for (int r = 0; r < 32; ++r) { a0 += red[(r * 8 + qq) * 8 + j]; a1 += red[(r * 8 + qq) * 8 + 4 + j]; }
+      const int slot = blockIdx.x & (MMVQA_STAT_SLOTS - 1);
+      double* d = stat + ((size_t)slot * C + ch) * 2;
+      atomicAdd(d, a0);
+      atomicAdd(d + 1, a1);
+    }
+  }
+}
+
+// y = x * act'(pre)   (squeeze-excite gate backward on [B, C] tensors)
+__global__ void mul_dact_kernel(const float* __restrict__ x, const float* __restrict__ pre, int act,
+                                float* __restrict__ y, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = x[i] * act_bwd(act, pre[i]);
+}
+
+static inline int pix_grid(long npix, int cgroups) {
+  long g = (npix + 31) / 32;
+  long cap = 4096 / (cgroups > 0 ? cgroups : 1);
+  if (cap < 8) cap = 8;
+  if (g > cap) g = cap;
+  return (int)(g < 1 ? 1 : g);
+}
+
+int k_bn_act_add(hipStream_t st, const float* z, const float* s, const float* b, int pre_act, const float* idn,
+                 const float* ids, const float* idb, int idn_act, int post_act, float* out, long rows, int C) {
+  long n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_act_add_kernel, dim3(grid_for(n4)), dim3(256), 0, st, z, s, b, pre_act, idn, ids, idb,
+                     idn_act, post_act, out, n4, C / 4);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_dwconv_fwd(hipStream_t st, const float* z1, const float* s1, const float* b1, const float* w, float* z2,
+                 double* stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad) {
+  if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(pix_grid((long)N * OH * OW, C / 32), C / 32), dim3(256), 0, st, z1, s1, b1,
+                     w, z2, stat, N, H, W, C, OH, OW, stride, pad);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_dwconv_bwd_data(hipStream_t st, const float* g2, const float* z2, const float* P, const float* Q,
+                      const float* R, const float* w, const float* z1, const float* s1, const float* b1,
+                      const float* mean1, const float* invstd1, float* g1, double* stat, int N, int H, int W, int C,
+                      int OH, int OW, int stride, int pad) {
+  if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
+  hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(pix_grid((long)N * H * W, C / 32), C / 32), dim3(256), 0, st, g2, z2,
+                     P, Q, R, w, z1, s1, b1, mean1, invstd1, g1, stat, N, H, W, C, OH, OW, stride, pad);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_dwconv_bwd_weight(hipStream_t st, const float* g2, const float* z2, const float* P, const float* Q,
+                        const float* R, const float* z1, const float* s1, const float* b1, float* dw, int N, int H,
+                        int W, int C, int OH, int OW, int stride, int pad) {
+  if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
+  int g = pix_grid((long)N * OH * OW, C / 32);
+  if (g > 64) g = 64;   // every workgroup ends with 288 atomics per 32 channels
+  hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(g, C / 32), dim3(256), 0, st, g2, z2, P, Q, R, z1, s1, b1, dw, N,
+                     H, W, C, OH, OW, stride, pad);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_se_pool(hipStream_t st, const float* z, const float* s, const float* b, float* pool, int N, int HW, int C) {
+  hipLaunchKernelGGL(se_pool_kernel, dim3(cdiv_i(C / 4, 64), N), dim3(64), 0, st, z, s, b, pool, HW, C);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_se_dgate(hipStream_t st, const float* t, const float* z, const float* s, const float* b, float* dgate, int N,
+               int HW, int C) {
+  hipLaunchKernelGGL(se_dgate_kernel, dim3(cdiv_i(C / 4, 64), N), dim3(64), 0, st, t, z, s, b, dgate, HW, C);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_act_bwd_stats(hipStream_t st, const float* t, const float* gate, const float* add, const float* z,
+                    const float* s, const float* b, const float* mean, const float* invstd, int act, float* out,
+                    double* stat, long npix, int HW, int C) {
+  if (C % 4) return mmvqa_set_error(MMVQA_ERR_ARG, "act_bwd_stats: C=%d must be a multiple of 4", C);
+  const int cg = (C + 31) / 32;
+  hipLaunchKernelGGL(act_bwd_stats_kernel, dim3(pix_grid(npix, cg), cg), dim3(256), 0, st, t, gate, add, z, s, b,
+                     mean, invstd, act, out, stat, npix, HW, C);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_mul_dact(hipStream_t st, const float* x, const float* pre, int act, float* y, long n) {
+  hipLaunchKernelGGL(mul_dact_kernel, dim3(cdiv_i(n, 256)), dim3(256), 0, st, x, pre, act, y, n);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}

@@ -87,9 +87,64 @@ int build_tables(mmvqa_engine* e) {
   e->emb_type = b.add(be + "token_type_embeddings.weight", 0, {d.type_vocab, H});
   e->emb_ln = b.ln(be + "LayerNorm", H);
   // models/image_encoding.py:43-62 -- backbone + tap convs
-  if (d.cnn != 0) return mmvqa_set_error(MMVQA_ERR_ARG, "engine: cnn=%d not built yet (resnet only)", d.cnn);
   const std::string rm = "transformer.trans.model.";
   const int w = d.resnet_width;
+  if (d.cnn == 1) {
+    // timm tf_efficientnetv2_m(features_only=True) -- architecture: SURVEY.md Appendix B (wiring unpinned)
+    struct St { int type, rep, stride, exp, out; bool se; };
+    const St arch[7] = {{0, 3, 1, 1, 24, false}, {1, 5, 2, 4, 48, false}, {1, 5, 2, 4, 80, false}, {2, 7, 2, 4, 160, true},
+                        {2, 14, 1, 6, 176, true}, {2, 18, 2, 6, 304, true}, {2, 5, 1, 6, 512, true}};
+    const int feat_of_stage[7] = {0, 1, 2, -1, 3, -1, 4};
+    const int div = d.effnet_depth_div > 0 ? d.effnet_depth_div : 1;
+    e->stem_conv = b.conv(rm + "conv_stem", 3, 24, 3, 2, 0);
+    e->stem_bn = b.bn(rm + "bn1", 24, 1);
+    e->stem_bn.eps = 1e-3f;
+    int cin = 24;
+    for (int sI = 0; sI < 7; ++sI) {
+      const St& a = arch[sI];
+      const int reps = std::max(1, (a.rep + div - 1) / div);
+      for (int k = 0; k < reps; ++k) {
+        EffBlock blk;
+        const std::string p = rm + "blocks." + std::to_string(sI) + "." + std::to_string(k) + ".";
+        blk.type = a.type; blk.cin = cin; blk.cout = a.out; blk.stride = k == 0 ? a.stride : 1;
+        blk.skip = blk.stride == 1 && cin == a.out;
+        blk.mid = cin * a.exp;
+        if (a.type == 0) {
+          blk.c_a = b.conv(p + "conv", cin, a.out, 3, blk.stride, 0);
+          blk.b_a = b.bn(p + "bn1", a.out, 1);
+        } else if (a.type == 1) {
+          blk.c_a = b.conv(p + "conv_exp", cin, blk.mid, 3, blk.stride, 0);
+          blk.b_a = b.bn(p + "bn1", blk.mid, 1);
+          blk.c_p = b.conv(p + "conv_pwl", blk.mid, a.out, 1, 1, 0);
+          blk.b_p = b.bn(p + "bn2", a.out, 1);
+        } else {
+          blk.rd = (int)std::lround(cin * 0.25);
+          blk.c_a = b.conv(p + "conv_pw", cin, blk.mid, 1, 1, 0);
+          blk.b_a = b.bn(p + "bn1", blk.mid, 1);
+          blk.dw_w = b.add(p + "conv_dw.weight", 0, {blk.mid, 1, 3, 3}, 1);
+          blk.b_dw = b.bn(p + "bn2", blk.mid, 1);
+          blk.se_r.in = blk.mid; blk.se_r.out = blk.rd;
+          blk.se_r.w = b.add(p + "se.conv_reduce.weight", 0, {blk.rd, blk.mid, 1, 1}, 1);
+          blk.se_r.b = b.add(p + "se.conv_reduce.bias", 0, {blk.rd});
+          blk.se_e.in = blk.rd; blk.se_e.out = blk.mid;
+          blk.se_e.w = b.add(p + "se.conv_expand.weight", 0, {blk.mid, blk.rd, 1, 1}, 1);
+          blk.se_e.b = b.add(p + "se.conv_expand.bias", 0, {blk.mid});
+          blk.c_p = b.conv(p + "conv_pwl", blk.mid, a.out, 1, 1, 0);
+          blk.b_p = b.bn(p + "bn3", a.out, 1);
+        }
+        blk.b_a.eps = blk.b_dw.eps = blk.b_p.eps = 1e-3f;
+        blk.feature = (k == reps - 1) ? feat_of_stage[sI] : -1;
+        cin = a.out;
+        e->eff.push_back(blk);
+      }
+    }
+    const char* tapn[5] = {"conv2", "conv3", "conv4", "conv5", "conv7"};
+    const int tapc[5] = {24, 48, 80, 176, 512};
+    for (int k = 0; k < 5; ++k) {
+      e->taps[k].C = tapc[k];
+      e->taps[k].w = b.add(std::string("transformer.trans.") + tapn[k] + ".weight", 0, {H, tapc[k], 1, 1}, 1);
+    }
+  } else if (d.cnn == 0) {
   e->stem_conv = b.conv(rm + "conv1", 3, w, 7, 2, 3);
   e->stem_bn = b.bn(rm + "bn1", w, 5);
   int inpl = w;
@@ -122,6 +177,9 @@ int build_tables(mmvqa_engine* e) {
   for (int k = 0; k < 5; ++k) {
     e->taps[k].C = tapc[k];
     e->taps[k].w = b.add(std::string("transformer.trans.") + tapn[k] + ".weight", 0, {H, tapc[k], 1, 1}, 1);
+  }
+  } else {
+    return mmvqa_set_error(MMVQA_ERR_ARG, "engine: unknown cnn=%d", d.cnn);
   }
   // encoder
   if (d.encoder == 0) {
@@ -210,6 +268,60 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
   const int H = d.hidden;
   const size_t M = (size_t)B * T;
   // ---- backbone
+  size_t max_io = 0, max_mid = 0, max_tapM = 0;
+  if (d.cnn == 1) {
+    // TensorFlow SAME padding: out = ceil(in/s); the odd padding element goes to the end, so the leading pad is
+    // total/2 and the trailing one is implied by the bounds checks of the gather
+    auto same = [](int in, int k, int s2, int* out) {
+      *out = (in + s2 - 1) / s2;
+      int total = std::max((*out - 1) * s2 + k - in, 0);
+      return total / 2;
+    };
+    int ph = same(IH, 3, 2, &e->SH), pw = same(IW, 3, 2, &e->SW);
+    if (ph != pw) { mmvqa_set_error(MMVQA_ERR_ARG, "plan: image %dx%d needs different SAME pads per axis", IH, IW); return 0; }
+    e->stem_conv.pad = ph;
+    const size_t M0 = (size_t)B * e->SH * e->SW;
+    e->z0 = a.f(M0 * 24);
+    e->eff_a0 = a.f(M0 * 24);
+    plan_bn(a, e->stem_bn, (double)M0);
+    max_io = M0 * 24;
+    int h = e->SH, wd = e->SW;
+    size_t max_se = 0;
+    for (auto& blk : e->eff) {
+      blk.N = B; blk.H = h; blk.W = wd;
+      int p1 = same(h, 3, blk.stride, &blk.OH), p2 = same(wd, 3, blk.stride, &blk.OW);
+      if (p1 != p2) { mmvqa_set_error(MMVQA_ERR_ARG, "plan: map %dx%d needs different SAME pads per axis", h, wd); return 0; }
+      blk.pad = p1;
+      const size_t Min = (size_t)B * h * wd, Mout = (size_t)B * blk.OH * blk.OW;
+      if (blk.type == 0) {
+        blk.c_a.pad = p1;
+        blk.za = a.f(Mout * blk.cout); plan_bn(a, blk.b_a, (double)Mout);
+      } else if (blk.type == 1) {
+        blk.c_a.pad = p1;
+        blk.za = a.f(Mout * blk.mid); plan_bn(a, blk.b_a, (double)Mout);
+        blk.zp = a.f(Mout * blk.cout); plan_bn(a, blk.b_p, (double)Mout);
+        max_mid = std::max(max_mid, Mout * blk.mid);
+      } else {
+        blk.za = a.f(Min * blk.mid); plan_bn(a, blk.b_a, (double)Min);
+        blk.zdw = a.f(Mout * blk.mid); plan_bn(a, blk.b_dw, (double)Mout);
+        blk.zp = a.f(Mout * blk.cout); plan_bn(a, blk.b_p, (double)Mout);
+        blk.pool = a.f((size_t)B * blk.mid); blk.gpre = a.f((size_t)B * blk.mid); blk.gate = a.f((size_t)B * blk.mid);
+        blk.rpre = a.f((size_t)B * blk.rd); blk.r = a.f((size_t)B * blk.rd);
+        max_mid = std::max(max_mid, std::max(Min, Mout) * blk.mid);
+        max_se = std::max(max_se, (size_t)B * blk.mid);
+      }
+      blk.out = a.f(Mout * blk.cout);
+      max_io = std::max(max_io, std::max(Min * blk.cin, Mout * blk.cout));
+      if (blk.feature >= 0) { e->taps[blk.feature].HW = blk.OH * blk.OW; e->taps[blk.feature].M = (long)Mout; }
+      h = blk.OH; wd = blk.OW;
+    }
+    e->eff_gA = a.f(max_mid); e->eff_gB = a.f(max_mid);
+    for (int i = 0; i < 6; ++i) e->eff_se[i] = a.f(max_se + 64);
+    for (int k = 0; k < 5; ++k) {
+      max_tapM = std::max(max_tapM, (size_t)e->taps[k].M);
+      e->tapgrad[k] = a.f((size_t)e->taps[k].M * e->taps[k].C);
+    }
+  } else {
   e->SH = conv_out(IH, 7, 2, 3); e->SW = conv_out(IW, 7, 2, 3);
   e->PH = conv_out(e->SH, 3, 2, 1); e->PW = conv_out(e->SW, 3, 2, 1);
   const int w = d.resnet_width;
@@ -219,7 +331,7 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
   e->p0 = a.f((size_t)B * e->PH * e->PW * w);
   e->pool_idx = a.f(((size_t)B * e->PH * e->PW * w + 3) / 4);
   int h = e->PH, wd = e->PW;
-  size_t max_io = M0 * w, max_mid = 0, max_tapM = M0;
+  max_io = M0 * w; max_tapM = M0;
   for (auto& blk : e->blocks) {
     blk.N = B; blk.H = h; blk.W = wd;
     blk.OH = conv_out(h, 3, blk.c2.stride, 1); blk.OW = conv_out(wd, 3, blk.c2.stride, 1);
@@ -247,6 +359,7 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
   for (int k = 0; k < 5; ++k) {
     max_tapM = std::max(max_tapM, (size_t)e->taps[k].M);
     e->tapgrad[k] = a.f((size_t)e->taps[k].M * e->taps[k].C);
+  }
   }
   e->vis = a.f((size_t)5 * B * H);
   e->dvis = a.f((size_t)5 * B * H);
@@ -292,11 +405,13 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
     (bwd ? bn.stat_b : bn.stat_f) = sd;
     sd += (size_t)MMVQA_STAT_SLOTS * bn.C * 2;
   };
-  take(e->stem_bn, false);
-  for (auto& blk : e->blocks) { take(blk.b1, false); take(blk.b2, false); take(blk.b3, false); if (blk.has_ds) take(blk.bd, false); }
-  const size_t half = sd;
-  take(e->stem_bn, true);
-  for (auto& blk : e->blocks) { take(blk.b1, true); take(blk.b2, true); take(blk.b3, true); if (blk.has_ds) take(blk.bd, true); }
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool bw = pass == 1;
+    take(e->stem_bn, bw);
+    for (auto& blk : e->blocks) { take(blk.b1, bw); take(blk.b2, bw); take(blk.b3, bw); if (blk.has_ds) take(blk.bd, bw); }
+    for (auto& blk : e->eff) { take(blk.b_a, bw); if (blk.type == 2) take(blk.b_dw, bw); if (blk.type != 0) take(blk.b_p, bw); }
+  }
+  const size_t half = sd / 2;
   if (sd != 2 * half) { mmvqa_set_error(MMVQA_ERR_STATE, "plan: stat zone mismatch"); return 0; }
   e->statzone_floats = sd * 2;
   a.f(e->statzone_floats);
@@ -346,14 +461,14 @@ static GemmParams gp_linear_geom() {
 
 struct EpiOpt {
   const float* R = nullptr; int r_ld = 0;
-  const float* Mk = nullptr; int mk_ld = 0; const float* mk_s = nullptr; const float* mk_b = nullptr;
+  const float* Mk = nullptr; int mk_ld = 0; const float* mk_s = nullptr; const float* mk_b = nullptr; int mk_mode = 0;
   BNRef* st1 = nullptr; const float* Z1 = nullptr;
   BNRef* st2 = nullptr; const float* Z2 = nullptr;
 };
 
 static void apply_epi(mmvqa_engine* e, GemmParams& g, const EpiOpt& o) {
   g.R = o.R; g.r_ld = o.r_ld;
-  g.Mk = o.Mk; g.mk_ld = o.mk_ld; g.mk_s = o.mk_s; g.mk_b = o.mk_b;
+  g.Mk = o.Mk; g.mk_ld = o.mk_ld; g.mk_s = o.mk_s; g.mk_b = o.mk_b; g.mk_mode = o.mk_mode;
   if (o.st1) {
     g.stat1 = stat_ptr(e, o.st1->stat_b); g.stat_bwd = 1;
     g.Z1 = o.Z1; g.z1_ld = o.st1->C; g.mean1 = WS(o.st1->mean); g.invstd1 = WS(o.st1->invstd);
@@ -425,7 +540,7 @@ static void conv_geom(GemmParams& g, const ConvRef& c, int H, int W, int OH, int
 
 static int bn_coef_fwd(mmvqa_engine* e, hipStream_t st, BNRef& bn) {
   RUN(PROF_OTHER, 0,
-      k_bn_coef_fwd(st, stat_ptr(e, bn.stat_f), bn.C, bn.count, 1e-5f, PRM(bn.gamma), PRM(bn.beta),
+      k_bn_coef_fwd(st, stat_ptr(e, bn.stat_f), bn.C, bn.count, bn.eps, PRM(bn.gamma), PRM(bn.beta),
                     e->bufs + bn.rmean, e->bufs + bn.rvar, e->nbt + bn.nbt, 0.1f, bn.reps, e->training,
                     WS(bn.scale), WS(bn.shift), WS(bn.mean), WS(bn.invstd)));
   return MMVQA_OK;
@@ -682,6 +797,208 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
   return MMVQA_OK;
 }
 
+// --------------------------------------------------------------------------- EfficientNetV2 forward / backward
+// conv (1x1 / 3x3 SAME) whose input is silu(bn_in(x_raw)) [* squeeze-excite gate]; statistics of the output
+static int eff_conv_fwd(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const float* x, const BNRef* bn_in,
+                        const float* gate, int N, int H, int W, int OH, int OW, float* z, BNRef& bn_out) {
+  GemmParams g;
+  memset(&g, 0, sizeof(g));
+  g.M = N * OH * OW; g.N = c.Cout; g.K = c.KH * c.KH * c.Cin;
+  g.A = x; g.a_ld = c.Cin;
+  if (bn_in) {
+    g.a_pro = gate ? PRO_SILU_GATE : PRO_AFFINE_SILU;
+    g.a_c0 = WS(bn_in->scale); g.a_c1 = WS(bn_in->shift);
+    g.gate = gate; g.gate_hw = OH * OW;
+  }
+  g.g_SH = H; g.g_SW = W; g.g_Cs = c.Cin; g.g_OH = OH; g.g_OW = OW;
+  g.g_KH = g.g_KW = c.KH; g.g_stride = c.stride; g.g_pad = c.pad;
+  g.B = PRM(c.w); g.b_ld = g.K;
+  g.C = z; g.c_ld = c.Cout;
+  if (e->training) { g.stat1 = stat_ptr(e, bn_out.stat_f); g.stat_bwd = 0; }
+  RUN(PROF_IGEMM, 2.0 * g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
+  return bn_coef_fwd(e, st, bn_out);
+}
+
+static int eff_conv_wgrad(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const float* G, const float* z,
+                          const BNRef& bn_out, const float* x, const BNRef* bn_in, const float* gate, int N, int H,
+                          int W, int OH, int OW) {
+  GemmParams g;
+  memset(&g, 0, sizeof(g));
+  g.M = c.Cout; g.N = c.KH * c.KH * c.Cin; g.K = N * OH * OW;
+  g.A = G; g.A2 = z; g.a_ld = c.Cout; g.a_pro = PRO_DZ;
+  g.a_c0 = WS(bn_out.P); g.a_c1 = WS(bn_out.Q); g.a_c2 = WS(bn_out.R);
+  g.B = x; g.b_ld = c.Cin;
+  if (bn_in) {
+    g.b_pro = gate ? PRO_SILU_GATE : PRO_AFFINE_SILU;
+    g.b_c0 = WS(bn_in->scale); g.b_c1 = WS(bn_in->shift);
+    g.gate = gate; g.gate_hw = OH * OW;
+  }
+  g.g_SH = H; g.g_SW = W; g.g_Cs = c.Cin; g.g_OH = OH; g.g_OW = OW;
+  g.g_KH = g.g_KW = c.KH; g.g_stride = c.stride; g.g_pad = c.pad;
+  g.C = GRD(c.w); g.c_ld = g.N; g.c_atomic = 1;
+  RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_WGRAD, 0, 0, st));
+  return MMVQA_OK;
+}
+
+static int effnet_forward(mmvqa_engine* e, hipStream_t st) {
+  const mmvqa_model_desc& d = e->d;
+  const int B = e->B;
+  if (e->training)
+    HIP_CHECK_RET(hipMemsetAsync(stat_ptr(e, 0), 0, e->statzone_floats / 2 * sizeof(float), st));
+  HIP_CHECK_RET(hipMemsetAsync(WS(e->vis), 0, (size_t)5 * B * d.hidden * sizeof(float), st));
+  const long M0 = (long)B * e->SH * e->SW;
+  {  // conv_stem 3x3/2 SAME on the NCHW image
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = (int)M0; g.N = 24; g.K = 27;
+    g.A = e->img; g.g_nchw = 1;
+    g.g_SH = e->IH; g.g_SW = e->IW; g.g_Cs = 3; g.g_OH = e->SH; g.g_OW = e->SW;
+    g.g_KH = g.g_KW = 3; g.g_stride = 2; g.g_pad = e->stem_conv.pad;
+    g.B = PRM(e->stem_conv.w); g.b_ld = 27;
+    g.C = WS(e->z0); g.c_ld = 24;
+    if (e->training) g.stat1 = stat_ptr(e, e->stem_bn.stat_f);
+    RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 1, 0, st));
+    TRY(bn_coef_fwd(e, st, e->stem_bn));
+    RUN(PROF_OTHER, 0, k_bn_act_add(st, WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), ACT_SILU, nullptr, nullptr,
+                                    nullptr, 0, ACT_NONE, WS(e->eff_a0), M0, 24));
+  }
+  const float* x = WS(e->eff_a0);
+  for (auto& b : e->eff) {
+    const long Mout = (long)B * b.OH * b.OW;
+    const float* idn = b.skip ? x : nullptr;
+    if (b.type == 0) {
+      TRY(eff_conv_fwd(e, st, b.c_a, x, nullptr, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.za), b.b_a));
+      RUN(PROF_OTHER, 0, k_bn_act_add(st, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), ACT_SILU, idn, nullptr, nullptr, 0,
+                                      ACT_NONE, WS(b.out), Mout, b.cout));
+    } else if (b.type == 1) {
+      TRY(eff_conv_fwd(e, st, b.c_a, x, nullptr, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.za), b.b_a));
+      TRY(eff_conv_fwd(e, st, b.c_p, WS(b.za), &b.b_a, nullptr, B, b.OH, b.OW, b.OH, b.OW, WS(b.zp), b.b_p));
+      RUN(PROF_OTHER, 0, k_bn_act_add(st, WS(b.zp), WS(b.b_p.scale), WS(b.b_p.shift), ACT_NONE, idn, nullptr, nullptr, 0,
+                                      ACT_NONE, WS(b.out), Mout, b.cout));
+    } else {
+      TRY(eff_conv_fwd(e, st, b.c_a, x, nullptr, nullptr, B, b.H, b.W, b.H, b.W, WS(b.za), b.b_a));
+      RUN(PROF_OTHER, 0, k_dwconv_fwd(st, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), PRM(b.dw_w), WS(b.zdw),
+                                      e->training ? stat_ptr(e, b.b_dw.stat_f) : nullptr, B, b.H, b.W, b.mid, b.OH, b.OW,
+                                      b.stride, b.pad));
+      TRY(bn_coef_fwd(e, st, b.b_dw));
+      // squeeze-excite: gate = sigmoid(W_e silu(W_r mean_hw(a2) + b_r) + b_e)
+      RUN(PROF_OTHER, 0, k_se_pool(st, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift), WS(b.pool), B, b.OH * b.OW, b.mid));
+      TRY(lin_fwd(e, st, WS(b.pool), b.mid, B, b.se_r, WS(b.r), b.rd, ACT_SILU, WS(b.rpre), 0.f, 0, nullptr, 0));
+      TRY(lin_fwd(e, st, WS(b.r), b.rd, B, b.se_e, WS(b.gate), b.mid, ACT_SIGMOID, WS(b.gpre), 0.f, 0, nullptr, 0));
+      TRY(eff_conv_fwd(e, st, b.c_p, WS(b.zdw), &b.b_dw, WS(b.gate), B, b.OH, b.OW, b.OH, b.OW, WS(b.zp), b.b_p));
+      RUN(PROF_OTHER, 0, k_bn_act_add(st, WS(b.zp), WS(b.b_p.scale), WS(b.b_p.shift), ACT_NONE, idn, nullptr, nullptr, 0,
+                                      ACT_NONE, WS(b.out), Mout, b.cout));
+    }
+    x = WS(b.out);
+    if (b.feature >= 0) TRY(tap_fwd(e, st, b.feature, x, nullptr));
+  }
+  return MMVQA_OK;
+}
+
+static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
+  const int B = e->B;
+  HIP_CHECK_RET(hipMemsetAsync(stat_ptr(e, 0) + e->statzone_floats / 4, 0,
+                               e->statzone_floats / 2 * sizeof(float), st));
+  const int nb = (int)e->eff.size();
+  // a block whose last op is a BatchNorm (er / ir) expects the BN-backward sums of that BN with its gradient
+  auto producer_opts = [&](int i, EpiOpt& o) {
+    if (i < 0) return;
+    EffBlock& pb = e->eff[i];
+    if (pb.type != 0) { o.st1 = &pb.b_p; o.Z1 = WS(pb.zp); }
+  };
+  for (auto& b : e->eff)
+    if (b.feature >= 0 && b.feature < 4) TRY(tap_bwd(e, st, b.feature, WS(b.out), nullptr, WS(e->tapgrad[b.feature]), EpiOpt()));
+  int cur = 0;
+  {
+    EpiOpt o;
+    producer_opts(nb - 1, o);
+    TRY(tap_bwd(e, st, 4, WS(e->eff[nb - 1].out), nullptr, WS(e->gbuf[cur]), o));
+  }
+  for (int i = nb - 1; i >= 0; --i) {
+    EffBlock& b = e->eff[i];
+    const float* G = WS(e->gbuf[cur]);
+    const float* x = i == 0 ? WS(e->eff_a0) : WS(e->eff[i - 1].out);
+    float* Gprev = WS(e->gbuf[cur ^ 1]);
+    const float* extra = (i > 0 && e->eff[i - 1].feature >= 0) ? WS(e->tapgrad[e->eff[i - 1].feature]) : nullptr;
+    if (extra && b.skip) return mmvqa_set_error(MMVQA_ERR_STATE, "effnet_backward: tap gradient into a skip block");
+    const long Min = (long)B * b.H * b.W, Mout = (long)B * b.OH * b.OW;
+    float* gA = WS(e->eff_gA);
+    float* gB = WS(e->eff_gB);
+    const float* dz_first = nullptr;   // gradient tensor feeding the block's first convolution
+    if (b.type == 0) {
+      // out = silu(bn(za)) + x
+      RUN(PROF_OTHER, 0, k_act_bwd_stats(st, G, nullptr, nullptr, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift),
+                                         WS(b.b_a.mean), WS(b.b_a.invstd), ACT_SILU, gA, stat_ptr(e, b.b_a.stat_b), Mout,
+                                         b.OH * b.OW, b.cout));
+      dz_first = gA;
+    } else if (b.type == 1) {
+      TRY(bn_coef_bwd(e, st, b.b_p));
+      TRY(eff_conv_wgrad(e, st, b.c_p, G, WS(b.zp), b.b_p, WS(b.za), &b.b_a, nullptr, B, b.OH, b.OW, b.OH, b.OW));
+      EpiOpt o;
+      o.Mk = WS(b.za); o.mk_ld = b.mid; o.mk_s = WS(b.b_a.scale); o.mk_b = WS(b.b_a.shift); o.mk_mode = 1;
+      o.st1 = &b.b_a; o.Z1 = WS(b.za);
+      TRY(conv_dgrad(e, st, b.c_p, G, WS(b.zp), b.b_p, B, b.OH, b.OW, b.OH, b.OW, gA, o));
+      dz_first = gA;
+    } else {
+      TRY(bn_coef_bwd(e, st, b.b_p));
+      TRY(eff_conv_wgrad(e, st, b.c_p, G, WS(b.zp), b.b_p, WS(b.zdw), &b.b_dw, WS(b.gate), B, b.OH, b.OW, b.OH, b.OW));
+      TRY(conv_dgrad(e, st, b.c_p, G, WS(b.zp), b.b_p, B, b.OH, b.OW, b.OH, b.OW, gA, EpiOpt()));   // t = d(a2*gate)
+      // squeeze-excite backward
+      float* dgate = WS(e->eff_se[0]); float* dgpre = WS(e->eff_se[1]); float* drpre = WS(e->eff_se[2]);
+      float* dpool = WS(e->eff_se[3]);
+      RUN(PROF_OTHER, 0, k_se_dgate(st, gA, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift), dgate, B, b.OH * b.OW, b.mid));
+      RUN(PROF_OTHER, 0, k_mul_dact(st, dgate, WS(b.gpre), ACT_SIGMOID, dgpre, (long)B * b.mid));
+      TRY(lin_wgrad(e, st, dgpre, b.mid, WS(b.r), b.rd, B, b.se_e, true));
+      TRY(lin_dgrad(e, st, dgpre, b.mid, B, b.se_e, drpre, b.rd, ACT_SILU, WS(b.rpre), b.rd, GRD(b.se_r.b), nullptr, 0));
+      TRY(lin_wgrad(e, st, drpre, b.rd, WS(b.pool), b.mid, B, b.se_r, false));
+      TRY(lin_dgrad(e, st, drpre, b.rd, B, b.se_r, dpool, b.mid, 0, nullptr, 0, nullptr, nullptr, 0));
+      // du2 = (t*gate + dpool/HW) * silu'(bn2(zdw)); BN2 sums
+      RUN(PROF_OTHER, 0, k_act_bwd_stats(st, gA, WS(b.gate), dpool, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift),
+                                         WS(b.b_dw.mean), WS(b.b_dw.invstd), ACT_SILU, gB, stat_ptr(e, b.b_dw.stat_b), Mout,
+                                         b.OH * b.OW, b.mid));
+      TRY(bn_coef_bwd(e, st, b.b_dw));
+      RUN(PROF_OTHER, 0, k_dwconv_bwd_weight(st, gB, WS(b.zdw), WS(b.b_dw.P), WS(b.b_dw.Q), WS(b.b_dw.R), WS(b.za),
+                                             WS(b.b_a.scale), WS(b.b_a.shift), GRD(b.dw_w), B, b.H, b.W, b.mid, b.OH, b.OW,
+                                             b.stride, b.pad));
+      RUN(PROF_OTHER, 0, k_dwconv_bwd_data(st, gB, WS(b.zdw), WS(b.b_dw.P), WS(b.b_dw.Q), WS(b.b_dw.R), PRM(b.dw_w),
+                                           WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), WS(b.b_a.mean), WS(b.b_a.invstd), gA,
+                                           stat_ptr(e, b.b_a.stat_b), B, b.H, b.W, b.mid, b.OH, b.OW, b.stride, b.pad));
+      dz_first = gA;
+    }
+    // first convolution of the block: weight gradient, then the gradient wrt the block input
+    TRY(bn_coef_bwd(e, st, b.b_a));
+    const int fo_h = b.type == 2 ? b.H : b.OH, fo_w = b.type == 2 ? b.W : b.OW;   // its output resolution
+    TRY(eff_conv_wgrad(e, st, b.c_a, dz_first, WS(b.za), b.b_a, x, nullptr, nullptr, B, b.H, b.W, fo_h, fo_w));
+    EpiOpt o;
+    producer_opts(i - 1, o);
+    if (b.skip) { o.R = G; o.r_ld = b.cin; }
+    else if (extra) { o.R = extra; o.r_ld = b.cin; }
+    TRY(conv_dgrad(e, st, b.c_a, dz_first, WS(b.za), b.b_a, B, b.H, b.W, fo_h, fo_w, Gprev, o));
+    (void)Min;
+    cur ^= 1;
+  }
+  // stem: du0 = G(a0) * silu'(bn1(z0)); BN sums; 3x3 weight gradient on the NCHW image
+  float* g0 = WS(e->gbuf[cur ^ 1]);
+  const long M0 = (long)B * e->SH * e->SW;
+  RUN(PROF_OTHER, 0, k_act_bwd_stats(st, WS(e->gbuf[cur]), nullptr, nullptr, WS(e->z0), WS(e->stem_bn.scale),
+                                     WS(e->stem_bn.shift), WS(e->stem_bn.mean), WS(e->stem_bn.invstd), ACT_SILU, g0,
+                                     stat_ptr(e, e->stem_bn.stat_b), M0, e->SH * e->SW, 24));
+  TRY(bn_coef_bwd(e, st, e->stem_bn));
+  {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.M = 24; g.N = 27; g.K = (int)M0;
+    g.A = g0; g.A2 = WS(e->z0); g.a_ld = 24; g.a_pro = PRO_DZ;
+    g.a_c0 = WS(e->stem_bn.P); g.a_c1 = WS(e->stem_bn.Q); g.a_c2 = WS(e->stem_bn.R);
+    g.B = e->img; g.g_nchw = 1;
+    g.g_SH = e->IH; g.g_SW = e->IW; g.g_Cs = 3; g.g_OH = e->SH; g.g_OW = e->SW;
+    g.g_KH = g.g_KW = 3; g.g_stride = 2; g.g_pad = e->stem_conv.pad;
+    g.C = GRD(e->stem_conv.w); g.c_ld = 27; g.c_atomic = 1;
+    RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_WGRAD, 1, 0, st));
+  }
+  return MMVQA_OK;
+}
+
 // --------------------------------------------------------------------------- encoders
 static inline uint32_t site_seed(const mmvqa_engine* e, int layer, int site) {
   return e->seed + 0x9E3779B9u * (uint32_t)(layer * 8 + site + 1);
@@ -932,7 +1249,7 @@ int engine_forward(mmvqa_engine* e, hipStream_t st, const float* img, const long
   e->logits = logits; e->logits_ld = logits_ld; e->feat = feat;
   e->training = training; e->seed = seed;
   struct TunerScope { TunerScope(IgemmTuner* t) { mmvqa_set_tuner(t); } ~TunerScope() { mmvqa_set_tuner(nullptr); } } ts(&e->tuner);
-  TRY(resnet_forward(e, st));
+  if (d.cnn == 1) TRY(effnet_forward(e, st)); else TRY(resnet_forward(e, st));
   const float pe = training ? d.p_emb_drop : 0.f;
   RUN(PROF_OTHER, 0,
       k_embed_fwd(st, ids, seg, PRM(e->emb_word), PRM(e->emb_pos), PRM(e->emb_type), PRM(e->emb_ln.g),
@@ -958,7 +1275,7 @@ int engine_backward(mmvqa_engine* e, hipStream_t st, const float* dlogits, int d
       k_embed_bwd(st, WS(e->t_a), e->ids, e->seg, WS(e->emb_xhat), WS(e->emb_rstd), PRM(e->emb_ln.g),
                   GRD(e->emb_word), GRD(e->emb_pos), GRD(e->emb_type), GRD(e->emb_ln.g), GRD(e->emb_ln.b),
                   WS(e->dvis), e->B, e->T, d.hidden, d.num_vis, pe, site_seed(e, 100, 0), 0));
-  return resnet_backward(e, st);
+  return d.cnn == 1 ? effnet_backward(e, st) : resnet_backward(e, st);
 }
 
 int engine_create(const mmvqa_model_desc* desc, mmvqa_engine** out) {
@@ -969,7 +1286,7 @@ int engine_create(const mmvqa_model_desc* desc, mmvqa_engine** out) {
                            d.n_layers, d.num_vis);
   if (d.encoder == 0 && (d.heads < 1 || d.hidden % d.heads != 0))
     return mmvqa_set_error(MMVQA_ERR_ARG, "engine_create: heads=%d does not divide hidden=%d", d.heads, d.hidden);
-  if (d.resnet_width % 8 != 0)
+  if (d.cnn == 0 && d.resnet_width % 8 != 0)
     return mmvqa_set_error(MMVQA_ERR_ARG, "engine_create: resnet_width=%d must be a multiple of 8", d.resnet_width);
   mmvqa_engine* e = new mmvqa_engine();
   e->d = d;

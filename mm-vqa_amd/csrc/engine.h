@@ -17,6 +17,7 @@ struct TensorSpec {
 
 struct BNRef {
   int C = 0, reps = 1;
+  float eps = 1e-5f;
   long long gamma = 0, beta = 0, rmean = 0, rvar = 0, nbt = 0;
   // plan (offsets into workspace, floats; stats in doubles from ws_d)
   size_t stat_f = 0, stat_b = 0;  // double offsets
@@ -37,13 +38,6 @@ struct BlockRef {  // torchvision Bottleneck
   size_t z1 = 0, z2 = 0, z3 = 0, zd = 0, out = 0;  // workspace offsets
 };
 
-struct TapRef {
-  long long w = 0;
-  int C = 0;
-  int HW = 0;
-  long M = 0;
-};
-
 struct LinRef {
   long long w = 0, b = -1;
   int in = 0, out = 0;
@@ -51,6 +45,29 @@ struct LinRef {
 
 struct LNRef {
   long long g = 0, b = 0;
+};
+
+// timm EfficientNetV2 block: ConvBnAct (cn) | EdgeResidual / Fused-MBConv (er) | InvertedResidual / MBConv (ir)
+struct EffBlock {
+  int type = 0, cin = 0, cout = 0, mid = 0, rd = 0, stride = 1;
+  bool skip = false;
+  ConvRef c_a;        // cn: conv 3x3 | er: conv_exp 3x3 | ir: conv_pw 1x1
+  BNRef b_a;
+  long long dw_w = 0;  // ir: depthwise 3x3 weight [mid][3][3]
+  BNRef b_dw;         // ir: bn2
+  LinRef se_r, se_e;  // ir: squeeze-excite conv_reduce / conv_expand (1x1 with bias)
+  ConvRef c_p;        // er / ir: conv_pwl 1x1
+  BNRef b_p;          // er: bn2 | ir: bn3
+  int N = 0, H = 0, W = 0, OH = 0, OW = 0, pad = 0;
+  size_t za = 0, zdw = 0, zp = 0, out = 0, pool = 0, rpre = 0, r = 0, gpre = 0, gate = 0;
+  int feature = -1;   // index of the tap fed by this block's output, or -1
+};
+
+struct TapRef {
+  long long w = 0;
+  int C = 0;
+  int HW = 0;
+  long M = 0;
 };
 
 struct BertLayerRef {
@@ -76,6 +93,9 @@ struct mmvqa_engine {
   ConvRef stem_conv;
   BNRef stem_bn;
   std::vector<BlockRef> blocks;
+  std::vector<EffBlock> eff;     // EfficientNetV2 body (cnn == 1)
+  size_t eff_a0 = 0;             // materialised stem activation silu(bn1(conv_stem))
+  size_t eff_gA = 0, eff_gB = 0, eff_se[6];   // backward scratch ([pixels, mid] x2, squeeze-excite temporaries)
   int layer_end[4];          // index of last block of layer1..4
   TapRef taps[5];            // order of the reference's return tuple: conv2(l4),conv3(l3),conv4(l2),conv5(l1),conv7(stem)
   long long emb_word = 0, emb_pos = 0, emb_type = 0;

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
   uint32_t a_mask[NAC];                       // per-tap validity (gather) or 0/1 (plain)
   int a_c = 0, a_tap = 0;                     // channel / tap of this thread's k (gather form)
   int a_pix[NAC], a_y0[NAC], a_x0[NAC];       // NCHW stem only
+  int a_img[NAC];                             // PRO_SILU_GATE: image index of the row
   f32x4 ac0 = {1, 1, 1, 1}, ac1 = {0, 0, 0, 0}, ac2 = {0, 0, 0, 0};
   const int akm_x4 = tid % A_X4, akm_k0 = tid / A_X4;
   if constexpr (A_ROWK) {
@@ -127,10 +128,11 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
       const int row = m0 + a_r0 + RSTEP * r;
-      a_base[r] = 0; a_mask[r] = 0; a_pix[r] = 0; a_y0[r] = -(1 << 24); a_x0[r] = -(1 << 24);
+      a_base[r] = 0; a_mask[r] = 0; a_pix[r] = 0; a_y0[r] = -(1 << 24); a_x0[r] = -(1 << 24); a_img[r] = 0;
       if (row < p.M) {
         int n = row / OHW, rem = row - n * OHW;
         int oy = rem / p.g_OW, ox = rem - oy * p.g_OW;
+        a_img[r] = p.gate_hw > 0 ? row / p.gate_hw : 0;
         if constexpr (NCHW) {
           a_pix[r] = n; a_y0[r] = oy * s - p.g_pad; a_x0[r] = ox * s - p.g_pad;
         } else if (KIND == KIND_FWD) {
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
     for (int r = 0; r < NB_KM; ++r) { b_base[r] = k_begin + bkm_k0 + B_KSTEP * r; b_ok0[r] = 1; }  // pixel index
   }
 
-  f32x4 ra[NAC], ra2[NAC], rb[NBC];
+  f32x4 ra[NAC], ra2[NAC], rb[NBC], rb2[NBC];
   uint32_t a_ok = 0, b_ok = 0;   // bit r: chunk r holds real data
 
   f32x16 acc[TM][TN];
@@ -240,12 +242,14 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
     constexpr int APRO = decltype(APRO_T)::value;
     constexpr int BPRO = decltype(BPRO_T)::value;
     constexpr bool A_TWO = (APRO == PRO_DZ);
+    constexpr bool A_AFF = (APRO == PRO_AFFINE_RELU || APRO == PRO_AFFINE_SILU || APRO == PRO_SILU_GATE);
+    constexpr bool B_AFF = (BPRO == PRO_AFFINE_RELU || BPRO == PRO_AFFINE_SILU || BPRO == PRO_SILU_GATE);
 
     auto load_tile = [&](int kt) __attribute__((always_inline)) {
       if constexpr (A_ROWK && !NCHW) {
         const bool kvalid = a_tap < taps;
         const int toff = taptab[kvalid ? a_tap : 0];
-        if constexpr (APRO != PRO_NONE) {
+        if constexpr (A_AFF || A_TWO) {
           const int cc = kvalid ? a_c : 0;
           ac0 = ld4(p.a_c0 + cc); ac1 = ld4(p.a_c1 + cc);
           if constexpr (APRO == PRO_DZ) ac2 = ld4(p.a_c2 + cc);
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
           const int off = ok ? a_base[r] + toff + a_c : 0;
           ra[r] = ld4(p.A + off);
           if constexpr (A_TWO) ra2[r] = ld4(p.A2 + off);
+          if constexpr (APRO == PRO_SILU_GATE) ra2[r] = ld4(p.gate + (ok ? a_img[r] * p.g_Cs + a_c : 0));
           a_ok |= (ok ? 1u : 0u) << r;
         }
         a_c += adv_c; a_tap += adv_tap;
@@ -353,6 +358,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
             const bool ok = (m < p.K) && b_colvalid && sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW;
             const int off = ok ? ((n * p.g_SH + sy) * p.g_SW + sx) * p.b_ld + b_ci : 0;
             rb[r] = ld4(p.B + off);
+            if constexpr (BPRO == PRO_SILU_GATE) rb2[r] = ld4(p.gate + (ok ? n * p.g_Cs + b_ci : 0));   // gate_hw == OH*OW for the 1x1 projection
             b_ok |= (ok ? 1u : 0u) << r;
           } else {
             f32x4 v = {0, 0, 0, 0};
@@ -383,6 +389,12 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
           if constexpr (APRO == PRO_AFFINE_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { float t = v[j] * ac0[j] + ac1[j]; v[j] = t > 0.f ? t : 0.f; }
+          } else if constexpr (APRO == PRO_AFFINE_SILU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j] * ac0[j] + ac1[j]);
+          } else if constexpr (APRO == PRO_SILU_GATE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j] * ac0[j] + ac1[j]) * ra2[r][j];
           } else if constexpr (APRO == PRO_DZ) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = v[j] * ac0[j] + ra2[r][j] * ac1[j] + ac2[j];
@@ -405,6 +417,12 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
         if constexpr (KIND == KIND_WGRAD && !NCHW && BPRO == PRO_AFFINE_RELU) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { float t = v[j] * bc0[j] + bc1[j]; v[j] = t > 0.f ? t : 0.f; }
+        } else if constexpr (KIND == KIND_WGRAD && !NCHW && BPRO == PRO_AFFINE_SILU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j] * bc0[j] + bc1[j]);
+        } else if constexpr (KIND == KIND_WGRAD && !NCHW && BPRO == PRO_SILU_GATE) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j] * bc0[j] + bc1[j]) * rb2[r][j];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
@@ -511,15 +529,34 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
     using I0 = std::integral_constant<int, PRO_NONE>;
     using I1 = std::integral_constant<int, PRO_AFFINE_RELU>;
     using I2 = std::integral_constant<int, PRO_DZ>;
-    if constexpr (KIND == KIND_FWD) {
-      if (p.a_pro == PRO_AFFINE_RELU && !NCHW) run(I1{}, I0{}); else run(I0{}, I0{});
+    using I4 = std::integral_constant<int, PRO_AFFINE_SILU>;
+    using I5 = std::integral_constant<int, PRO_SILU_GATE>;
+    if constexpr (NCHW) {
+      if (KIND == KIND_WGRAD && p.a_pro == PRO_DZ) run(I2{}, I0{}); else run(I0{}, I0{});
+    } else if constexpr (KIND == KIND_FWD) {
+      switch (p.a_pro) {
+        case PRO_AFFINE_RELU: run(I1{}, I0{}); break;
+        case PRO_AFFINE_SILU: run(I4{}, I0{}); break;
+        case PRO_SILU_GATE: run(I5{}, I0{}); break;
+        default: run(I0{}, I0{});
+      }
     } else if constexpr (KIND == KIND_DGRAD) {
       if (p.a_pro == PRO_DZ) run(I2{}, I0{}); else run(I0{}, I0{});
     } else {
       if (p.a_pro == PRO_DZ) {
-        if (p.b_pro == PRO_AFFINE_RELU && !NCHW) run(I2{}, I1{}); else run(I2{}, I0{});
+        switch (p.b_pro) {
+          case PRO_AFFINE_RELU: run(I2{}, I1{}); break;
+          case PRO_AFFINE_SILU: run(I2{}, I4{}); break;
+          case PRO_SILU_GATE: run(I2{}, I5{}); break;
+          default: run(I2{}, I0{});
+        }
       } else {
-        if (p.b_pro == PRO_AFFINE_RELU && !NCHW) run(I0{}, I1{}); else run(I0{}, I0{});
+        switch (p.b_pro) {
+          case PRO_AFFINE_RELU: run(I0{}, I1{}); break;
+          case PRO_AFFINE_SILU: run(I0{}, I4{}); break;
+          case PRO_SILU_GATE: run(I0{}, I5{}); break;
+          default: run(I0{}, I0{});
+        }
       }
     }
   }
@@ -659,7 +696,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
     float* Cpre = p.Cpre;
     const float* Pre = p.Pre; const int dact = p.dact, pre_ld = p.pre_ld, act = p.act;
     const float* R = p.R; const int r_ld = p.r_ld;
-    const float* Mk = p.Mk; const int mk_ld = p.mk_ld;
+    const float* Mk = p.Mk; const int mk_ld = p.mk_ld, mk_mode = p.mk_mode;
     const float* Z1 = p.Z1; const float* Z2 = p.Z2; const int z1_ld = p.z1_ld, z2_ld = p.z2_ld;
     double* st1 = p.stat1; double* st2 = p.stat2; const int stat_bwd = p.stat_bwd;
     float* colsum = p.colsum;
@@ -702,8 +739,13 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
       if (R) v += ldv(R, (size_t)row * r_ld + col);
       if (Mk) {
         const f32x4 m = ldv(Mk, (size_t)row * mk_ld + col);
+        if (mk_mode == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (m[j] * mks[j] + mkb[j] > 0.f) ? v[j] : 0.f;
+          for (int j = 0; j < 4; ++j) v[j] = (m[j] * mks[j] + mkb[j] > 0.f) ? v[j] : 0.f;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= dsilu_f(m[j] * mks[j] + mkb[j]);
+        }
       }
       stv(C, (size_t)row * ldc + col, v);
       if (st1) {

@@ -56,3 +56,23 @@ int k_axpy(hipStream_t st, float* y, const float* x, float a, long n);
 int k_colsum(hipStream_t st, const float* x, int ld, int rows, int cols, float* out);
 int k_dropout(hipStream_t st, float* x, long n, float p, uint32_t seed);
 int k_dropout_copy(hipStream_t st, const float* x, float* y, long n, float p, uint32_t seed);
+
+// EfficientNetV2 pieces (elementwise.hip)
+int k_bn_act_add(hipStream_t st, const float* z, const float* s, const float* b, int pre_act, const float* idn,
+                 const float* ids, const float* idb, int idn_act, int post_act, float* out, long rows, int C);
+int k_dwconv_fwd(hipStream_t st, const float* z1, const float* s1, const float* b1, const float* w, float* z2,
+                 double* stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad);
+int k_dwconv_bwd_data(hipStream_t st, const float* g2, const float* z2, const float* P, const float* Q,
+                      const float* R, const float* w, const float* z1, const float* s1, const float* b1,
+                      const float* mean1, const float* invstd1, float* g1, double* stat, int N, int H, int W, int C,
+                      int OH, int OW, int stride, int pad);
+int k_dwconv_bwd_weight(hipStream_t st, const float* g2, const float* z2, const float* P, const float* Q,
+                        const float* R, const float* z1, const float* s1, const float* b1, float* dw, int N, int H,
+                        int W, int C, int OH, int OW, int stride, int pad);
+int k_se_pool(hipStream_t st, const float* z, const float* s, const float* b, float* pool, int N, int HW, int C);
+int k_se_dgate(hipStream_t st, const float* t, const float* z, const float* s, const float* b, float* dgate, int N,
+               int HW, int C);
+int k_act_bwd_stats(hipStream_t st, const float* t, const float* gate, const float* add, const float* z,
+                    const float* s, const float* b, const float* mean, const float* invstd, int act, float* out,
+                    double* stat, long npix, int HW, int C);
+int k_mul_dact(hipStream_t st, const float* x, const float* pre, int act, float* y, long n);

@@ -79,6 +79,14 @@ def test_model_protocol_on_cpu():
     n_backbone = sum(p.numel() for n, p in full.named_parameters() if n.startswith("transformer.trans.model."))
     assert n_backbone == 60192808                       # torchvision resnet152
     assert sum(p.numel() for p in full.parameters()) == 140_034_154 or True
+    # timm tf_efficientnetv2_m(features_only=True): published body size, oracle-identical state_dict
+    eff = mmvqa_amd.Model(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer"))
+    n_eff = sum(p.numel() for n, p in eff.named_parameters() if n.startswith("transformer.trans.model."))
+    assert n_eff == 52200436
+    ea = O.make_args(cnn_encoder="tf_efficientnetv2_m", effnet_depth_div=8, hidden_size=96, n_layers=1, vocab_size=50,
+                     emb_vocab=50, bert_max_pos=32)
+    esd, eosd = mmvqa_amd.Model(ea).state_dict(), O.OracleModel(ea).state_dict()
+    assert set(esd) == set(eosd) and all(esd[k].shape == eosd[k].shape for k in esd)
     with pytest.raises(NotImplementedError):
         mmvqa_amd.Model(O.make_args(transformer_model="lstm"))
     with pytest.raises(NotImplementedError):

@@ -147,6 +147,18 @@ def test_deeper_backbone_relu_taps():
     run_case(mini_args(resnet_layers=(2, 2, 3, 2), resnet_width=16, use_relu=True), B=2, T=32, hw=72, kind="mlm")
 
 
+@pytest.mark.parametrize("tm,hw", [("realformer", 64), ("transformer", 72)])
+def test_effnetv2_backbone(tm, hw):
+    """tf_efficientnetv2_m body (depth reduced 8x; widths, SE, depthwise, SAME padding as the full net)"""
+    run_case(mini_args(cnn_encoder="tf_efficientnetv2_m", effnet_depth_div=8, transformer_model=tm), B=3, T=12, hw=hw,
+             kind="mlm")
+
+
+def test_effnetv2_vqa_relu_taps():
+    run_case(mini_args(cnn_encoder="tf_efficientnetv2_m", effnet_depth_div=5, dataset="VQA-Med", vocab_size=23,
+                       use_relu=True), B=4, T=10, hw=64, kind="vqa")
+
+
 def test_full_width_hidden768():
     """real channel widths (64..2048) and hidden 768 with a one-block-per-layer backbone"""
     run_case(mini_args(resnet_width=64, hidden_size=768, n_layers=1, vocab_size=300, emb_vocab=300), B=2, T=32,
