@@ -44,8 +44,15 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, den
 B_PER_GPU, T, HW, VOCAB = 16, 32, 224, 30522
 
 
+CONFIG = 2   # BASELINE.json configs[1] (the metric's config); --config 3 = tf_efficientnetv2_m + realformer
+
+
 def make_args():
     from types import SimpleNamespace
+    if CONFIG == 3:
+        return SimpleNamespace(task="MLM", dataset="roco", transformer_model="realformer",
+                               cnn_encoder="tf_efficientnetv2_m", num_vis=5, hidden_size=768, n_layers=4, heads=12,
+                               hidden_dropout_prob=0.3, vocab_size=VOCAB, use_relu=False, max_position_embeddings=T)
     return SimpleNamespace(task="MLM", dataset="roco", transformer_model="transformer", cnn_encoder="resnet152",
                            num_vis=5, hidden_size=768, n_layers=4, heads=12, hidden_dropout_prob=0.3,
                            vocab_size=VOCAB, use_relu=False, max_position_embeddings=T)
@@ -89,7 +96,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3])
     a = ap.parse_args()
+    global CONFIG
+    CONFIG = a.config
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -166,11 +176,13 @@ def main():
                     algorithmic_gflop_per_step=g["flops"] / 1e9,
                     other_ms_per_step=dict(attention=pr["attention"]["ms"], elementwise=pr["other"]["ms"]))
 
-    out = dict(metric="samples/sec ROCO-MLM pretrain (resnet152+transformer, bs16/GPU, 224^2, seq32)",
+    wl = ("pretrain/roco_train.py MLM-only: resnet152 + transformer(4 layers, 12 heads), " if CONFIG == 2 else
+          "pretrain/roco_train.py MLM-only: tf_efficientnetv2_m + realformer(4 layers, 8 heads), ")
+    out = dict(metric="samples/sec ROCO-MLM pretrain (resnet152+transformer, bs16/GPU, 224^2, seq32)" if CONFIG == 2 else
+               "samples/sec ROCO-MLM pretrain (tf_efficientnetv2_m+realformer, bs16/GPU, 224^2, seq32)",
                value=value, unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=ms,
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload="pretrain/roco_train.py MLM-only: resnet152 + transformer(4 layers, 12 heads), "
-                                    "num_vis 5, hidden 768, vocab 30522, per-GPU batch 16, 224x224, T=32; "
+               config=dict(workload=wl + "num_vis 5, hidden 768, vocab 30522, per-GPU batch 16, 224x224, T=32; "
                                     "fwd + log_softmax/NLL + bwd + grad all-reduce + Adam; dropout on, train-mode BN; "
                                     "random-init weights",
                            global_batch=B_PER_GPU * world, seq_len=T, parallelism=f"dp{world}",
