@@ -149,7 +149,12 @@ int mmvqa_dropout(mmvqa_stream_t s, float* x, long n, float p, uint32_t seed) {
 
 // ---------------------------------------------------------------------------------- engine
 int mmvqa_engine_create(const mmvqa_model_desc* desc, mmvqa_engine** out) { return engine_create(desc, out); }
-void mmvqa_engine_destroy(mmvqa_engine* e) { delete e; }
+void mmvqa_engine_destroy(mmvqa_engine* e) {
+  if (!e) return;
+  for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+  if (e->side) (void)hipStreamDestroy(e->side);
+  delete e;
+}
 int mmvqa_engine_num_tensors(const mmvqa_engine* e) { return e ? (int)e->specs.size() : 0; }
 int mmvqa_engine_tensor_info(const mmvqa_engine* e, int i, char* name, int name_cap, int* kind, int* ndim,
                              long long shape[4], long long* offset, int* channels_last) {

@@ -654,6 +654,48 @@ static int tap_bwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, co
   return MMVQA_OK;
 }
 
+// --------------------------------------------------------------------------- side stream (backward overlap)
+// The data-gradient chain (dgrad -> BN coefficients -> dgrad ...) is the critical path of the backward pass
+// and, on the 14x14 / 7x7 layers, fills well under one workgroup per CU; the weight-gradient GEMMs and
+// the tap backward only feed the optimizer, so they run on a second HIP stream and fill the idle CUs.
+// Ordering is by events: fork() makes the side stream wait for everything enqueued so far on the main
+// stream, mark() returns an event for the side work enqueued so far, need() makes the main stream wait
+// for such an event before it overwrites a buffer the side work reads.
+struct SideCtx {
+  mmvqa_engine* e;
+  hipStream_t st, sd;
+  bool on;
+  SideCtx(mmvqa_engine* e_, hipStream_t st_) : e(e_), st(st_) {
+    on = e->use_side && !e->prof_on && !e->tuner.tuning;
+    if (on && !e->side) on = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess;
+    sd = on ? e->side : st;
+  }
+  hipEvent_t next_event() {
+    if (e->ev_next == e->ev_pool.size()) {
+      hipEvent_t ev;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+      e->ev_pool.push_back(ev);
+    }
+    return e->ev_pool[e->ev_next++];
+  }
+  void fork() {
+    if (!on) return;
+    hipEvent_t ev = next_event();
+    if (!ev) return;
+    (void)hipEventRecord(ev, st);
+    (void)hipStreamWaitEvent(sd, ev, 0);
+  }
+  hipEvent_t mark() {
+    if (!on) return nullptr;
+    hipEvent_t ev = next_event();
+    if (ev) (void)hipEventRecord(ev, sd);
+    return ev;
+  }
+  void need(hipEvent_t ev) {
+    if (on && ev) (void)hipStreamWaitEvent(st, ev, 0);
+  }
+};
+
 // --------------------------------------------------------------------------- ResNet forward / backward
 static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
   const mmvqa_model_desc& d = e->d;
@@ -707,15 +749,11 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
   const int B = e->B, w = e->d.resnet_width;
   HIP_CHECK_RET(hipMemsetAsync(stat_ptr(e, 0) + e->statzone_floats / 4, 0,
                                e->statzone_floats / 2 * sizeof(float), st));
+  SideCtx sc(e, st);
+  hipStream_t sd = sc.sd;
   const int nb = (int)e->blocks.size();
-  // taps on layer1..3 and the stem produce side gradients T_k; the layer4 tap starts the main chain
-  for (int k = 1; k <= 3; ++k) {
-    const BlockRef& blk = e->blocks[e->layer_end[3 - k]];
-    TRY(tap_bwd(e, st, k, WS(blk.out), nullptr, WS(e->tapgrad[k]), EpiOpt()));
-  }
-  TRY(tap_bwd(e, st, 4, WS(e->z0), &e->stem_bn, WS(e->tapgrad[4]), EpiOpt()));
   int cur = 0;
-  {
+  {  // the layer4 tap starts the main chain
     BlockRef& last = e->blocks[nb - 1];
     EpiOpt o;
     o.Mk = WS(last.out); o.mk_ld = last.c3.Cout;
@@ -723,6 +761,18 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
     if (last.has_ds) { o.st2 = &last.bd; o.Z2 = WS(last.zd); }
     TRY(tap_bwd(e, st, 0, WS(last.out), nullptr, WS(e->gbuf[cur]), o));
   }
+  // taps on layer1..3 and the stem produce side gradients T_k that are only needed when the chain reaches
+  // their layer: side stream (they share the `du` scratch with the tap above, hence the fork after it)
+  hipEvent_t ev_tap[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  sc.fork();
+  for (int k = 1; k <= 3; ++k) {
+    const BlockRef& blk = e->blocks[e->layer_end[3 - k]];
+    TRY(tap_bwd(e, sd, k, WS(blk.out), nullptr, WS(e->tapgrad[k]), EpiOpt()));
+    ev_tap[k] = sc.mark();
+  }
+  TRY(tap_bwd(e, sd, 4, WS(e->z0), &e->stem_bn, WS(e->tapgrad[4]), EpiOpt()));
+  ev_tap[4] = sc.mark();
+  hipEvent_t ev_g1 = nullptr, ev_g2 = nullptr, ev_prevG = nullptr;   // side readers of g1buf / g2buf / previous G
   for (int i = nb - 1; i >= 0; --i) {
     BlockRef& b = e->blocks[i];
     const float* G = WS(e->gbuf[cur]);
@@ -730,29 +780,39 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
     float* Gprev = WS(e->gbuf[cur ^ 1]);
     // side gradient arriving at this block's input from a tap (only where the previous block ends a layer)
     const float* extra = nullptr;
+    hipEvent_t ev_extra = nullptr;
     for (int l = 0; l < 3; ++l)
-      if (i - 1 == e->layer_end[l]) extra = WS(e->tapgrad[3 - l]);
+      if (i - 1 == e->layer_end[l]) { extra = WS(e->tapgrad[3 - l]); ev_extra = ev_tap[3 - l]; }
+    hipEvent_t evG = nullptr;   // side readers of this block's G
     // conv3 / bn3
     TRY(bn_coef_bwd(e, st, b.b3));
-    TRY(conv_wgrad(e, st, b.c3, G, WS(b.z3), b.b3, WS(b.z2), &b.b2, B, b.OH, b.OW, b.OH, b.OW));
+    sc.fork();
+    TRY(conv_wgrad(e, sd, b.c3, G, WS(b.z3), b.b3, WS(b.z2), &b.b2, B, b.OH, b.OW, b.OH, b.OW));
+    evG = sc.mark();
     {
       EpiOpt o;
       o.Mk = WS(b.z2); o.mk_ld = b.c2.Cout; o.mk_s = WS(b.b2.scale); o.mk_b = WS(b.b2.shift);
       o.st1 = &b.b2; o.Z1 = WS(b.z2);
+      sc.need(ev_g2);
       TRY(conv_dgrad(e, st, b.c3, G, WS(b.z3), b.b3, B, b.OH, b.OW, b.OH, b.OW, WS(e->g2buf), o));
     }
     // conv2 / bn2
     TRY(bn_coef_bwd(e, st, b.b2));
-    TRY(conv_wgrad(e, st, b.c2, WS(e->g2buf), WS(b.z2), b.b2, WS(b.z1), &b.b1, B, b.H, b.W, b.OH, b.OW));
+    sc.fork();
+    TRY(conv_wgrad(e, sd, b.c2, WS(e->g2buf), WS(b.z2), b.b2, WS(b.z1), &b.b1, B, b.H, b.W, b.OH, b.OW));
+    ev_g2 = sc.mark();
     {
       EpiOpt o;
       o.Mk = WS(b.z1); o.mk_ld = b.c1.Cout; o.mk_s = WS(b.b1.scale); o.mk_b = WS(b.b1.shift);
       o.st1 = &b.b1; o.Z1 = WS(b.z1);
+      sc.need(ev_g1);
       TRY(conv_dgrad(e, st, b.c2, WS(e->g2buf), WS(b.z2), b.b2, B, b.H, b.W, b.OH, b.OW, WS(e->g1buf), o));
     }
     // conv1 / bn1
     TRY(bn_coef_bwd(e, st, b.b1));
-    TRY(conv_wgrad(e, st, b.c1, WS(e->g1buf), WS(b.z1), b.b1, x, nullptr, B, b.H, b.W, b.H, b.W));
+    sc.fork();
+    TRY(conv_wgrad(e, sd, b.c1, WS(e->g1buf), WS(b.z1), b.b1, x, nullptr, B, b.H, b.W, b.H, b.W));
+    ev_g1 = sc.mark();
     // gradient wrt the block input: conv1 path + identity/downsample path (+ tap side gradient)
     EpiOpt o;
     if (i > 0) {
@@ -763,20 +823,27 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
     }
     if (b.has_ds) {
       TRY(bn_coef_bwd(e, st, b.bd));
-      TRY(conv_wgrad(e, st, b.cd, G, WS(b.zd), b.bd, x, nullptr, B, b.H, b.W, b.OH, b.OW));
+      sc.fork();
+      TRY(conv_wgrad(e, sd, b.cd, G, WS(b.zd), b.bd, x, nullptr, B, b.H, b.W, b.OH, b.OW));
+      evG = sc.mark();
       EpiOpt od;
       od.R = extra; od.r_ld = b.cd.Cin;
+      sc.need(ev_extra);
       TRY(conv_dgrad(e, st, b.cd, G, WS(b.zd), b.bd, B, b.H, b.W, b.OH, b.OW, WS(e->dstmp), od));
       o.R = WS(e->dstmp); o.r_ld = b.c1.Cin;
     } else {
       if (extra) return mmvqa_set_error(MMVQA_ERR_STATE, "resnet_backward: tap gradient without downsample");
       o.R = G; o.r_ld = b.c1.Cin;
     }
+    sc.need(ev_prevG);   // the buffer written next was the G of the block before: its side readers must be done
     TRY(conv_dgrad(e, st, b.c1, WS(e->g1buf), WS(b.z1), b.b1, B, b.H, b.W, b.H, b.W, Gprev, o));
+    ev_prevG = evG;
     cur ^= 1;
   }
   // stem: max-pool backward + stem-tap gradient + ReLU mask + BN statistics, then the 7x7 weight gradient
   float* g0 = WS(e->gbuf[cur ^ 1]);
+  sc.need(ev_prevG);
+  sc.need(ev_tap[4]);
   RUN(PROF_OTHER, 0,
       k_maxpool_bwd(st, WS(e->gbuf[cur]), reinterpret_cast<unsigned char*>(WS(e->pool_idx)), WS(e->tapgrad[4]),
                     WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), WS(e->stem_bn.mean),
@@ -794,6 +861,7 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
     g.C = GRD(e->stem_conv.w); g.c_ld = 147; g.c_atomic = 1;
     RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_WGRAD, 1, 0, st));
   }
+  sc.need(sc.mark());   // join: everything after the backward (all-reduce, Adam) sees the side stream's gradients
   return MMVQA_OK;
 }
 
@@ -1266,6 +1334,7 @@ int engine_backward(mmvqa_engine* e, hipStream_t st, const float* dlogits, int d
   if (!e->planned || !e->bound || !e->img) return mmvqa_set_error(MMVQA_ERR_STATE, "engine_backward: run forward first");
   const mmvqa_model_desc& d = e->d;
   struct TunerScope { TunerScope(IgemmTuner* t) { mmvqa_set_tuner(t); } ~TunerScope() { mmvqa_set_tuner(nullptr); } } ts(&e->tuner);
+  e->ev_next = 0;
   const float* h = WS(e->enc_out_final);
   TRY(heads_backward(e, st, h, dlogits, dl_ld, dfeat));
   if (d.encoder == 0) TRY(bert_backward(e, st, WS(e->emb_out)));

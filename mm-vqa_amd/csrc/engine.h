@@ -131,6 +131,11 @@ struct mmvqa_engine {
   float* feat = nullptr;
   // ---- per-shape kernel configuration
   IgemmTuner tuner;
+  // ---- second stream: weight-gradient GEMMs and tap backward run beside the data-gradient chain
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_next = 0;
+  int use_side = 1;
   // ---- profiling
   int prof_on = 0;
   struct ProfRec { hipEvent_t a, b; int cls; double flops; };
