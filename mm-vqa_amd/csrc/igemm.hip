@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
   int a_c = 0, a_tap = 0;                     // channel / tap of this thread's k (gather form)
   int a_pix[NAC], a_y0[NAC], a_x0[NAC];       // NCHW stem only
   int a_img[NAC];                             // PRO_SILU_GATE: image index of the row
-  f32x4 ac0 = {1, 1, 1, 1}, ac1 = {0, 0, 0, 0}, ac2 = {0, 0, 0, 0};
+  f32x4 ac0_i = {1, 1, 1, 1}, ac1_i = {0, 0, 0, 0}, ac2_i = {0, 0, 0, 0};   // WGRAD: loop-invariant A' coefficients
   const int akm_x4 = tid % A_X4, akm_k0 = tid / A_X4;
   if constexpr (A_ROWK) {
     {
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
       a_mask[r] = (i < p.M) ? 1u : 0u;
     }
     if (p.a_pro != PRO_NONE && i < p.M) {   // channel = output row index i: loop invariant
-      ac0 = ld4(p.a_c0 + i); ac1 = ld4(p.a_c1 + i);
-      if (p.a_pro == PRO_DZ) ac2 = ld4(p.a_c2 + i);
+      ac0_i = ld4(p.a_c0 + i); ac1_i = ld4(p.a_c1 + i);
+      if (p.a_pro == PRO_DZ) ac2_i = ld4(p.a_c2 + i);
     }
   }
 
@@ -221,8 +221,12 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
     for (int r = 0; r < NB_KM; ++r) { b_base[r] = k_begin + bkm_k0 + B_KSTEP * r; b_ok0[r] = 1; }  // pixel index
   }
 
-  f32x4 ra[NAC], ra2[NAC], rb[NBC], rb2[NBC];
-  uint32_t a_ok = 0, b_ok = 0;   // bit r: chunk r holds real data
+  // register staging of one K-tile in flight (two of them for the software-pipelined small-tile loop)
+  struct Stage {
+    f32x4 ra[NAC], ra2[NAC], rb[NBC], rb2[NBC];
+    uint32_t a_ok, b_ok;       // bit r: chunk r holds real data
+    f32x4 ac0, ac1, ac2;      // A-prologue coefficients of this tile's channels
+  };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -245,24 +249,24 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
     constexpr bool A_AFF = (APRO == PRO_AFFINE_RELU || APRO == PRO_AFFINE_SILU || APRO == PRO_SILU_GATE);
     constexpr bool B_AFF = (BPRO == PRO_AFFINE_RELU || BPRO == PRO_AFFINE_SILU || BPRO == PRO_SILU_GATE);
 
-    auto load_tile = [&](int kt) __attribute__((always_inline)) {
+    auto load_tile = [&](Stage& S, int kt) __attribute__((always_inline)) {
       if constexpr (A_ROWK && !NCHW) {
         const bool kvalid = a_tap < taps;
         const int toff = taptab[kvalid ? a_tap : 0];
         if constexpr (A_AFF || A_TWO) {
           const int cc = kvalid ? a_c : 0;
-          ac0 = ld4(p.a_c0 + cc); ac1 = ld4(p.a_c1 + cc);
-          if constexpr (APRO == PRO_DZ) ac2 = ld4(p.a_c2 + cc);
+          S.ac0 = ld4(p.a_c0 + cc); S.ac1 = ld4(p.a_c1 + cc);
+          if constexpr (APRO == PRO_DZ) S.ac2 = ld4(p.a_c2 + cc);
         }
-        a_ok = 0;
+        S.a_ok = 0;
 #pragma unroll
         for (int r = 0; r < NA; ++r) {
           const bool ok = kvalid && ((a_mask[r] >> (a_tap & 31)) & 1u);
           const int off = ok ? a_base[r] + toff + a_c : 0;
-          ra[r] = ld4(p.A + off);
-          if constexpr (A_TWO) ra2[r] = ld4(p.A2 + off);
-          if constexpr (APRO == PRO_SILU_GATE) ra2[r] = ld4(p.gate + (ok ? a_img[r] * p.g_Cs + a_c : 0));
-          a_ok |= (ok ? 1u : 0u) << r;
+          S.ra[r] = ld4(p.A + off);
+          if constexpr (A_TWO) S.ra2[r] = ld4(p.A2 + off);
+          if constexpr (APRO == PRO_SILU_GATE) S.ra2[r] = ld4(p.gate + (ok ? a_img[r] * p.g_Cs + a_c : 0));
+          S.a_ok |= (ok ? 1u : 0u) << r;
         }
         a_c += adv_c; a_tap += adv_tap;
         const bool wrap = a_c >= p.g_Cs;
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
           ekh[j] = tap / p.g_KW; ekw[j] = tap - ekh[j] * p.g_KW;
           if (kk >= p.K) ekh[j] = -(1 << 24);
         }
-        a_ok = ~0u;
+        S.a_ok = ~0u;
 #pragma unroll
         for (int r = 0; r < NA; ++r) {
           f32x4 v = {0, 0, 0, 0};
@@ -290,37 +294,37 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
             if (sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW)
               v[j] = p.A[((size_t)(a_pix[r] * p.g_Cs + ec[j]) * p.g_SH + sy) * p.g_SW + sx];
           }
-          ra[r] = v;
+          S.ra[r] = v;
         }
       } else {
         // WGRAD A': element (k = pixel, i = channel) at A[k*a_ld + i]
-        a_ok = 0;
+        S.a_ok = 0;
         const int kk0 = kt * BK + akm_k0;
 #pragma unroll
         for (int r = 0; r < NA_KM; ++r) {
           const bool ok = a_mask[r] && (kk0 + A_KSTEP * r < p.K);
           const int off = ok ? a_base[r] : 0;
-          ra[r] = ld4(p.A + off);
-          if constexpr (A_TWO) ra2[r] = ld4(p.A2 + off);
-          a_ok |= (ok ? 1u : 0u) << r;
+          S.ra[r] = ld4(p.A + off);
+          if constexpr (A_TWO) S.ra2[r] = ld4(p.A2 + off);
+          S.a_ok |= (ok ? 1u : 0u) << r;
           a_base[r] += BK * p.a_ld;
         }
       }
       // ---------------- B
       if constexpr (KIND == KIND_FWD) {
         const int k = kt * BK + b_kq;
-        b_ok = 0;
+        S.b_ok = 0;
         if constexpr (!NCHW) {
           const bool kvalid = k < p.K;
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
             const bool ok = kvalid && b_ok0[r];
-            rb[r] = ld4(p.B + (ok ? b_base[r] : 0));
-            b_ok |= (ok ? 1u : 0u) << r;
+            S.rb[r] = ld4(p.B + (ok ? b_base[r] : 0));
+            S.b_ok |= (ok ? 1u : 0u) << r;
             b_base[r] += BK;
           }
         } else {
-          b_ok = ~0u;
+          S.b_ok = ~0u;
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
             f32x4 v = {0, 0, 0, 0};
@@ -328,25 +332,25 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
 #pragma unroll
               for (int j = 0; j < 4; ++j) if (k + j < p.K) v[j] = p.B[b_base[r] + j];
             }
-            rb[r] = v;
+            S.rb[r] = v;
             b_base[r] += BK;
           }
         }
       } else if constexpr (KIND == KIND_DGRAD) {
-        b_ok = 0;
+        S.b_ok = 0;
 #pragma unroll
         for (int r = 0; r < NB_KM; ++r) {
           const bool ok = b_colvalid && (b_tap[r] < taps);
           const int off = ok ? b_co[r] * p.b_ld + b_tap[r] * p.b_tapstride + b_base[r] : 0;
-          rb[r] = ld4(p.B + off);
-          b_ok |= (ok ? 1u : 0u) << r;
+          S.rb[r] = ld4(p.B + off);
+          S.b_ok |= (ok ? 1u : 0u) << r;
           b_co[r] += adv_c; b_tap[r] += adv_tap;
           const bool wrap = b_co[r] >= p.g_Cs;
           b_co[r] = wrap ? b_co[r] - p.g_Cs : b_co[r];
           b_tap[r] = wrap ? b_tap[r] + 1 : b_tap[r];
         }
       } else {
-        b_ok = 0;
+        S.b_ok = 0;
 #pragma unroll
         for (int r = 0; r < NB_KM; ++r) {
           const int m = b_base[r];
@@ -357,9 +361,9 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
             const int sy = oy * s - p.g_pad + b_kh, sx = ox * s - p.g_pad + b_kw;
             const bool ok = (m < p.K) && b_colvalid && sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW;
             const int off = ok ? ((n * p.g_SH + sy) * p.g_SW + sx) * p.b_ld + b_ci : 0;
-            rb[r] = ld4(p.B + off);
-            if constexpr (BPRO == PRO_SILU_GATE) rb2[r] = ld4(p.gate + (ok ? n * p.g_Cs + b_ci : 0));   // gate_hw == OH*OW for the 1x1 projection
-            b_ok |= (ok ? 1u : 0u) << r;
+            S.rb[r] = ld4(p.B + off);
+            if constexpr (BPRO == PRO_SILU_GATE) S.rb2[r] = ld4(p.gate + (ok ? n * p.g_Cs + b_ci : 0));   // gate_hw == OH*OW for the 1x1 projection
+            S.b_ok |= (ok ? 1u : 0u) << r;
           } else {
             f32x4 v = {0, 0, 0, 0};
             if (m < p.K) {
@@ -370,34 +374,34 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
                   v[j] = p.B[((size_t)(n * p.g_Cs + b_cc[j]) * p.g_SH + sy) * p.g_SW + sx];
               }
             }
-            rb[r] = v;
-            b_ok = ~0u;
+            S.rb[r] = v;
+            S.b_ok = ~0u;
           }
         }
       }
     };
 
     // registers -> LDS (+ prologues) for ONE chunk c (A chunks first, then B); selects only, no branches
-    auto store_chunk = [&](int buf, int kt, int c) __attribute__((always_inline)) {
+    auto store_chunk = [&](Stage& S, int buf, int kt, int c) __attribute__((always_inline)) {
       float* as = As + buf * A_TILE;
       float* bs = Bs + buf * B_TILE;
       if (c < NAC) {
         const int r = c;
-        f32x4 v = ra[r];
-        const bool ok = (a_ok >> r) & 1u;
+        f32x4 v = S.ra[r];
+        const bool ok = (S.a_ok >> r) & 1u;
         if constexpr (!(NCHW && A_ROWK)) {   // (the stem's gathered image operand is zero-filled, no prologue)
           if constexpr (APRO == PRO_AFFINE_RELU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { float t = v[j] * ac0[j] + ac1[j]; v[j] = t > 0.f ? t : 0.f; }
+            for (int j = 0; j < 4; ++j) { float t = v[j] * S.ac0[j] + S.ac1[j]; v[j] = t > 0.f ? t : 0.f; }
           } else if constexpr (APRO == PRO_AFFINE_SILU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j] * ac0[j] + ac1[j]);
+            for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j] * S.ac0[j] + S.ac1[j]);
           } else if constexpr (APRO == PRO_SILU_GATE) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j] * ac0[j] + ac1[j]) * ra2[r][j];
+            for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j] * S.ac0[j] + S.ac1[j]) * S.ra2[r][j];
           } else if constexpr (APRO == PRO_DZ) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = v[j] * ac0[j] + ra2[r][j] * ac1[j] + ac2[j];
+            for (int j = 0; j < 4; ++j) v[j] = v[j] * S.ac0[j] + S.ra2[r][j] * S.ac1[j] + S.ac2[j];
           }
           // ragged K / M (vocab-sized dimension): elements of the float4 beyond the end are zeroed
           const int e0 = A_ROWK ? (kt * BK + a_kq) : (m0 + akm_x4 * 4);
@@ -412,8 +416,8 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
         }
       } else {
         const int r = c - NAC;
-        f32x4 v = rb[r];
-        const bool ok = (b_ok >> r) & 1u;
+        f32x4 v = S.rb[r];
+        const bool ok = (S.b_ok >> r) & 1u;
         if constexpr (KIND == KIND_WGRAD && !NCHW && BPRO == PRO_AFFINE_RELU) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { float t = v[j] * bc0[j] + bc1[j]; v[j] = t > 0.f ? t : 0.f; }
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
           for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j] * bc0[j] + bc1[j]);
         } else if constexpr (KIND == KIND_WGRAD && !NCHW && BPRO == PRO_SILU_GATE) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j] * bc0[j] + bc1[j]) * rb2[r][j];
+          for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j] * bc0[j] + bc1[j]) * S.rb2[r][j];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
@@ -460,43 +464,55 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
     constexpr int K0 = NKG / 2;                           // first k-group after which chunks are written
     constexpr int PER = (NC + (NKG - K0) - 1) / (NKG - K0);
 
+    Stage S0, S1;
+    S0.a_ok = S0.b_ok = S1.a_ok = S1.b_ok = 0;
+    S0.ac0 = S1.ac0 = ac0_i; S0.ac1 = S1.ac1 = ac1_i; S0.ac2 = S1.ac2 = ac2_i;
+
     if (nkt > 0) {
-      load_tile(kt_begin);
+      load_tile(S0, kt_begin);
 #pragma unroll
-      for (int c = 0; c < NC; ++c) store_chunk(0, kt_begin, c);
+      for (int c = 0; c < NC; ++c) store_chunk(S0, 0, kt_begin, c);
     }
     __syncthreads();
 
-    // Software pipeline of one K-tile (single barrier):
-    //   fragments of k-group kk+1 are read from LDS while the MFMAs of kk run;
-    //   the global loads of tile t+1 are issued behind the first MFMA group (their address
-    //   arithmetic runs in the shadow of the matrix pipe);
-    //   the LDS writes of tile t+1 (other buffer: last read one barrier ago) are spread over the
-    //   second half of the MFMA groups instead of forming a bubble before the barrier.
     if constexpr (TM * TN == 1) {
-      for (int t = 0; t < nkt; ++t) {
+      // Software pipeline of the small tile (one barrier per K-tile, global loads TWO tiles ahead):
+      //   fragments of k-group kk+1 are read from LDS while the MFMAs of kk run;
+      //   the global loads of tile t+2 are issued behind the first MFMA group of tile t (address
+      //   arithmetic in the shadow of the matrix pipe) into the register stage that was drained one
+      //   iteration ago, so a load has a whole K-tile of MFMAs to arrive (measured: with one tile of
+      //   distance 35 % of the wave cycles were spent in s_waitcnt/barrier);
+      //   the LDS writes of tile t+1 (other buffer, last read one barrier ago) are spread over the second
+      //   half of the MFMA groups instead of forming a bubble before the barrier.
+      auto body = [&](int t, Stage& Sload, Stage& Sstore) __attribute__((always_inline)) {
         const int buf = t & 1;
         const float* as = As + buf * A_TILE;
         const float* bs = Bs + buf * B_TILE;
         f32x4 fa[2][TM], fb[2][TN];
         read_frags(as, bs, ks, fa[0], fb[0]);
-  #pragma unroll
+#pragma unroll
         for (int kk = 0; kk < NKG; ++kk) {
           if (kk + 1 < NKG) read_frags(as, bs, (kk + 1) * KS + ks, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
-  #pragma unroll
+#pragma unroll
           for (int j = 0; j < 4; ++j)
-  #pragma unroll
+#pragma unroll
             for (int a = 0; a < TM; ++a)
-  #pragma unroll
+#pragma unroll
               for (int b = 0; b < TN; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][a][j], fb[kk & 1][b][j], acc[a][b], 0, 0, 0);
-          if (kk == 0) load_tile(kt_begin + t + 1);   // unconditional: past the end everything is masked
+          if (kk == 0) load_tile(Sload, kt_begin + t + 2);   // unconditional: past the end everything is masked
           if (kk >= K0) {
-  #pragma unroll
-            for (int c = (kk - K0) * PER; c < (kk - K0 + 1) * PER && c < NC; ++c) store_chunk(buf ^ 1, kt_begin + t + 1, c);
+#pragma unroll
+            for (int c = (kk - K0) * PER; c < (kk - K0 + 1) * PER && c < NC; ++c)
+              store_chunk(Sstore, buf ^ 1, kt_begin + t + 1, c);
           }
         }
         __syncthreads();
+      };
+      if (nkt > 0) load_tile(S1, kt_begin + 1);
+      for (int t = 0; t < nkt; t += 2) {
+        body(t, S0, S1);
+        if (t + 1 < nkt) body(t + 1, S1, S0);
       }
     } else {
       // large wave tiles (16-64 MFMAs per k-group, two workgroups per CU): plain order, the second
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
         const int buf = t & 1;
         const float* as = As + buf * A_TILE;
         const float* bs = Bs + buf * B_TILE;
-        load_tile(kt_begin + t + 1);
+        load_tile(S0, kt_begin + t + 1);
 #pragma unroll
         for (int kk = 0; kk < NKG; ++kk) {
           f32x4 fa[TM], fb[TN];
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
         }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) store_chunk(buf ^ 1, kt_begin + t + 1, c);
+        for (int c = 0; c < NC; ++c) store_chunk(S0, buf ^ 1, kt_begin + t + 1, c);
         __syncthreads();
       }
     }
