@@ -170,8 +170,13 @@ def main():
         model.profile(False)
         g = pr["igemm"]
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "round1_igemm_traffic.json")
+        if CONFIG == 2 and os.path.exists(tf):   # HBM bytes per launch from the committed rocprofv3 PMC passes
+            traffic = json.load(open(tf))["igemm"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/round1_igemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)"
         roof = dict(bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None, kernel="igemm_kernel (fp32 MFMA implicit GEMM)",
+                    frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src, kernel="igemm_kernel (fp32 MFMA implicit GEMM)",
                     launches_per_step=g["launches"], avg_launch_us=g["ms"] * 1e3 / max(1, g["launches"]),
                     algorithmic_gflop_per_step=g["flops"] / 1e9,
                     other_ms_per_step=dict(attention=pr["attention"]["ms"], elementwise=pr["other"]["ms"]))
