@@ -125,6 +125,8 @@ def main():
     model.set_seed(1234 + rank)
     opt = mmvqa_amd.FusedAdam(model, lr=2e-5)
     red = GradReducer(model.flat_grads)
+    if world > 1:
+        model.set_grad_ready_hook(red.start)   # all-reduce of finished gradient ranges overlaps the backbone backward
     img, ids, seg, mask, tgt = synth.roco_batch(B_PER_GPU, T, HW, VOCAB, seed=1234 + rank, device=dev)
 
     def step():

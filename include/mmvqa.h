@@ -141,6 +141,9 @@ typedef struct mmvqa_model_desc {
   float p_rf_drop;      /* RealFormer dp1/dp2 (0.1) */
 } mmvqa_model_desc;
 
+/* gradient-ready notification of mmvqa_engine_set_grad_callback: grads[lo, hi) (float offsets) are final */
+typedef void (*mmvqa_grad_cb)(void* user, long long lo, long long hi);
+
 typedef struct mmvqa_engine mmvqa_engine;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -235,6 +238,11 @@ int mmvqa_engine_forward(mmvqa_engine* e, mmvqa_stream_t s, const float* img, co
 /* accumulates into grads; dlogits same layout as logits; dfeat nullable */
 int mmvqa_engine_backward(mmvqa_engine* e, mmvqa_stream_t s, const float* dlogits, int dlogits_ld,
                           const float* dfeat);
+/* data-parallel overlap: cb(user, lo, hi) is called on the HOST thread inside mmvqa_engine_backward as soon as
+ * the kernels completing grads[lo, hi) (float offsets) are enqueued and the given stream is ordered behind them, so
+ * the caller can start the all-reduce of that range on its communication stream while backward continues.
+ * The ranges of one backward partition [0, param_floats) exactly.  NULL disables. */
+int mmvqa_engine_set_grad_callback(mmvqa_engine* e, mmvqa_grad_cb cb, void* user);
 /* per-shape kernel configuration: while enabled, every implicit-GEMM shape met for the first time in
  * forward/backward is timed over its candidate (tile, split-K) set and the fastest is kept for later
  * calls.  A pass run with tuning enabled is a throw-away pass (outputs/statistics are garbage).

@@ -110,6 +110,7 @@ SIGNATURES = {
     "mmvqa_engine_bind": (_i, [_P, _P, _P, _P, _P, _P, _sz]),
     "mmvqa_engine_forward": (_i, [_P, _P, _P, _P, _P, _P, _P, _i, _P, _i, _u32]),
     "mmvqa_engine_backward": (_i, [_P, _P, _P, _i, _P]),
+    "mmvqa_engine_set_grad_callback": (_i, [_P, _P, _P]),
     "mmvqa_engine_tune": (_i, [_P, _i]),
     "mmvqa_engine_profile": (_i, [_P, _i]),
     "mmvqa_engine_profile_read": (_i, [_P, _i, C.POINTER(_ll), C.POINTER(_d), C.POINTER(_d)]),

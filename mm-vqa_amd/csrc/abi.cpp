@@ -204,6 +204,12 @@ int mmvqa_engine_backward(mmvqa_engine* e, mmvqa_stream_t s, const float* dlogit
   if (!e || !dlogits) return mmvqa_set_error(MMVQA_ERR_ARG, "backward: null pointer");
   return engine_backward(e, ST(s), dlogits, dlogits_ld, dfeat);
 }
+int mmvqa_engine_set_grad_callback(mmvqa_engine* e, mmvqa_grad_cb cb, void* user) {
+  if (!e) return mmvqa_set_error(MMVQA_ERR_ARG, "set_grad_callback: null engine");
+  e->grad_cb = cb;
+  e->grad_cb_user = user;
+  return MMVQA_OK;
+}
 int mmvqa_engine_tune(mmvqa_engine* e, int enable) {
   if (!e) return mmvqa_set_error(MMVQA_ERR_ARG, "tune: null engine");
   e->tuner.tuning = enable != 0;

@@ -86,6 +86,7 @@ int build_tables(mmvqa_engine* e) {
   e->emb_pos = b.add(be + "position_embeddings.weight", 0, {d.max_pos, H});
   e->emb_type = b.add(be + "token_type_embeddings.weight", 0, {d.type_vocab, H});
   e->emb_ln = b.ln(be + "LayerNorm", H);
+  e->emb_hi = b.align4(e->n_params);
   // models/image_encoding.py:43-62 -- backbone + tap convs
   const std::string rm = "transformer.trans.model.";
   const int w = d.resnet_width;
@@ -182,6 +183,7 @@ int build_tables(mmvqa_engine* e) {
     return mmvqa_set_error(MMVQA_ERR_ARG, "engine: unknown cnn=%d", d.cnn);
   }
   // encoder
+  e->enc_lo = b.align4(e->n_params);
   if (d.encoder == 0) {
     const std::string bl = "transformer.blocks.";
     e->norm1 = b.ln(bl + "norm1", H);
@@ -696,6 +698,12 @@ struct SideCtx {
   }
 };
 
+static void notify(mmvqa_engine* e, SideCtx& sc, long long lo, long long hi) {
+  if (!e->grad_cb || hi <= lo) return;
+  sc.need(sc.mark());   // weight gradients of the range may still be queued on the side stream
+  e->grad_cb(e->grad_cb_user, lo, hi);
+}
+
 // --------------------------------------------------------------------------- ResNet forward / backward
 static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
   const mmvqa_model_desc& d = e->d;
@@ -773,6 +781,7 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
   TRY(tap_bwd(e, sd, 4, WS(e->z0), &e->stem_bn, WS(e->tapgrad[4]), EpiOpt()));
   ev_tap[4] = sc.mark();
   hipEvent_t ev_g1 = nullptr, ev_g2 = nullptr, ev_prevG = nullptr;   // side readers of g1buf / g2buf / previous G
+  long long hi_mark = e->enc_lo;    // gradients in [hi_mark, end) were announced by the caller; fc + taps sit below
   for (int i = nb - 1; i >= 0; --i) {
     BlockRef& b = e->blocks[i];
     const float* G = WS(e->gbuf[cur]);
@@ -839,6 +848,10 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
     TRY(conv_dgrad(e, st, b.c1, WS(e->g1buf), WS(b.z1), b.b1, B, b.H, b.W, b.H, b.W, Gprev, o));
     ev_prevG = evG;
     cur ^= 1;
+    // announce finished gradient ranges every ~12 blocks and at layer starts (large, few all-reduces)
+    bool layer_start = false;
+    for (int l = 0; l < 3; ++l) layer_start |= (i - 1 == e->layer_end[l]);
+    if (i > 0 && (layer_start || (nb - i) % 12 == 0)) { notify(e, sc, b.c1.w, hi_mark); hi_mark = b.c1.w; }
   }
   // stem: max-pool backward + stem-tap gradient + ReLU mask + BN statistics, then the 7x7 weight gradient
   float* g0 = WS(e->gbuf[cur ^ 1]);
@@ -862,6 +875,7 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
     RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_WGRAD, 1, 0, st));
   }
   sc.need(sc.mark());   // join: everything after the backward (all-reduce, Adam) sees the side stream's gradients
+  notify(e, sc, e->emb_hi, hi_mark);
   return MMVQA_OK;
 }
 
@@ -968,6 +982,8 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
   HIP_CHECK_RET(hipMemsetAsync(stat_ptr(e, 0) + e->statzone_floats / 4, 0,
                                e->statzone_floats / 2 * sizeof(float), st));
   const int nb = (int)e->eff.size();
+  SideCtx scx(e, st);
+  long long hi_mark = e->enc_lo;
   // a block whose last op is a BatchNorm (er / ir) expects the BN-backward sums of that BN with its gradient
   auto producer_opts = [&](int i, EpiOpt& o) {
     if (i < 0) return;
@@ -1044,6 +1060,7 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
     TRY(conv_dgrad(e, st, b.c_a, dz_first, WS(b.za), b.b_a, B, b.H, b.W, fo_h, fo_w, Gprev, o));
     (void)Min;
     cur ^= 1;
+    if (i > 0 && (nb - i) % 12 == 0) { notify(e, scx, b.c_a.w, hi_mark); hi_mark = b.c_a.w; }
   }
   // stem: du0 = G(a0) * silu'(bn1(z0)); BN sums; 3x3 weight gradient on the NCHW image
   float* g0 = WS(e->gbuf[cur ^ 1]);
@@ -1064,6 +1081,7 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
     g.C = GRD(e->stem_conv.w); g.c_ld = 27; g.c_atomic = 1;
     RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_WGRAD, 1, 0, st));
   }
+  notify(e, scx, e->emb_hi, hi_mark);
   return MMVQA_OK;
 }
 
@@ -1339,11 +1357,13 @@ int engine_backward(mmvqa_engine* e, hipStream_t st, const float* dlogits, int d
   TRY(heads_backward(e, st, h, dlogits, dl_ld, dfeat));
   if (d.encoder == 0) TRY(bert_backward(e, st, WS(e->emb_out)));
   else TRY(rf_backward(e, st, WS(e->emb_out)));
+  if (e->grad_cb) e->grad_cb(e->grad_cb_user, e->enc_lo, e->n_params);   // heads + encoder gradients are final
   const float pe = e->training ? d.p_emb_drop : 0.f;
   RUN(PROF_OTHER, 0,
       k_embed_bwd(st, WS(e->t_a), e->ids, e->seg, WS(e->emb_xhat), WS(e->emb_rstd), PRM(e->emb_ln.g),
                   GRD(e->emb_word), GRD(e->emb_pos), GRD(e->emb_type), GRD(e->emb_ln.g), GRD(e->emb_ln.b),
                   WS(e->dvis), e->B, e->T, d.hidden, d.num_vis, pe, site_seed(e, 100, 0), 0));
+  if (e->grad_cb) e->grad_cb(e->grad_cb_user, 0, e->emb_hi);            // embedding tables + LayerNorm
   return d.cnn == 1 ? effnet_backward(e, st) : resnet_backward(e, st);
 }
 

@@ -136,6 +136,11 @@ struct mmvqa_engine {
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
   int use_side = 1;
+  // ---- gradient-ready notifications (data-parallel overlap): called on the host right after the kernels that
+  // complete grads[lo, hi) have been enqueued and the main stream has been ordered behind them
+  void (*grad_cb)(void* user, long long lo, long long hi) = nullptr;
+  void* grad_cb_user = nullptr;
+  long long enc_lo = 0, emb_hi = 0;
   // ---- profiling
   int prof_on = 0;
   struct ProfRec { hipEvent_t a, b; int cls; double flops; };

@@ -30,9 +30,13 @@ class GradReducer:
             self.buckets.append((lo, hi))
             hi = lo
         self.pending = []
+        self.launched = 0
 
     def start(self, lo=0, hi=None):
-        """launch async all-reduce (SUM) of every bucket inside [lo, hi)"""
+        """launch async all-reduce (SUM) of every bucket inside [lo, hi).  This is the gradient-ready hook of
+        Model.set_grad_ready_hook: called from inside backward, the collective is ordered behind the kernels
+        that produced the range (the communication stream waits for the current stream at call time) and runs
+        beside the rest of the backward pass."""
         if world() == 1:
             return
         hi = self.flat.numel() if hi is None else hi
@@ -40,14 +44,18 @@ class GradReducer:
             a2, b2 = max(a, lo), min(b, hi)
             if a2 < b2:
                 self.pending.append(dist.all_reduce(self.flat[a2:b2], op=dist.ReduceOp.SUM, async_op=True))
+        self.launched += max(0, hi - lo)
 
     def finish(self):
+        """all-reduce whatever backward did not announce (no hook installed), then wait for everything"""
+        if world() > 1 and self.launched == 0:
+            self.start()
         for w in self.pending:
             w.wait()
         self.pending = []
+        self.launched = 0
 
     def allreduce(self):
-        self.start()
         self.finish()
 
 

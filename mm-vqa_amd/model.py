@@ -346,6 +346,9 @@ class Model(nn.Module):
         if dfeat is not None:
             dfeat = dfeat.contiguous()
         L.check(L.lib().mmvqa_engine_backward(self._handle, L.stream_ptr(), L.ptr(g), gld, L.ptr(dfeat)))
+        if getattr(self, "_cb_error", None) is not None:
+            err, self._cb_error = self._cb_error, None
+            raise err
         self.attach_grads()
 
     def forward(self, img, input_ids, segment_ids, input_mask):
@@ -353,6 +356,26 @@ class Model(nn.Module):
         if self.dataset == "VQA-Med":
             return out, 0, 0   # models/mmbert.py:167
         return out
+
+    # ------------------------------------------------------------------ data-parallel overlap
+    def set_grad_ready_hook(self, fn):
+        """fn(lo, hi) is called during backward as soon as flat_grads[lo:hi] is final (ordered on the current
+        stream), in an order that partitions the whole buffer; pass None to remove.  Used by ddp.GradReducer to
+        start the RCCL all-reduce of finished ranges while the backbone backward is still running."""
+        self._cb_error = None
+        if fn is None:
+            self._cb = None
+            L.check(L.lib().mmvqa_engine_set_grad_callback(self._handle, None, None))
+            return
+
+        def tramp(_user, lo, hi):
+            try:
+                fn(int(lo), int(hi))
+            except BaseException as ex:   # exceptions cannot cross the C frame
+                self._cb_error = ex
+
+        self._cb = C.CFUNCTYPE(None, C.c_void_p, C.c_longlong, C.c_longlong)(tramp)
+        L.check(L.lib().mmvqa_engine_set_grad_callback(self._handle, C.cast(self._cb, C.c_void_p), None))
 
     # ------------------------------------------------------------------ per-shape kernel tuning
     def tune(self, img, input_ids, segment_ids, input_mask):
@@ -364,6 +387,9 @@ class Model(nn.Module):
         was_training = self.training
         self.train()
         L.check(min(0, lib.mmvqa_engine_tune(self._handle, 1)))
+        cb = getattr(self, "_cb", None)
+        if cb is not None:   # the throw-away pass must not trigger gradient all-reduces
+            L.check(lib.mmvqa_engine_set_grad_callback(self._handle, None, None))
         try:
             out = self._engine_forward(img, input_ids, segment_ids, input_mask)
             logits = out[0] if isinstance(out, tuple) else out
@@ -372,6 +398,8 @@ class Model(nn.Module):
             torch.cuda.synchronize()
         finally:
             n = lib.mmvqa_engine_tune(self._handle, 0)
+            if cb is not None:
+                L.check(lib.mmvqa_engine_set_grad_callback(self._handle, C.cast(cb, C.c_void_p), None))
             self._flat[1].copy_(bufs)
             self._flat[2].copy_(nbt)
             self._flat_grad.zero_()

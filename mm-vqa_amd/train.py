@@ -93,7 +93,10 @@ def build(args, ctx, n_classes=None):
     model.set_seed(args.seed + ctx.rank)
     opt = FusedAdam(model, lr=args.lr)
     sched = lr_scheduler.ReduceLROnPlateau(_SchedShim(opt), patience=args.patience, factor=args.factor)
-    return model, opt, sched, GradReducer(model.flat_grads)
+    red = GradReducer(model.flat_grads)
+    if ctx.world > 1:
+        model.set_grad_ready_hook(red.start)
+    return model, opt, sched, red
 
 
 class _SchedShim(torch.optim.Optimizer):

@@ -327,3 +327,29 @@ def test_dropout_training_mode():
     fd = (lp - lm) / (2 * eps)
     an = float((ga * d).sum())
     assert abs(fd - an) <= 0.1 * max(abs(an), 1e-3), (fd, an)
+
+
+def test_grad_ready_ranges_partition_the_buffer():
+    """data-parallel overlap: the ranges announced during backward tile [0, n_params) exactly once, and by the
+    time a range is announced the current stream is ordered behind its gradients (values equal the final ones)"""
+    for kw in (dict(resnet_layers=(2, 2, 14, 2), resnet_width=8), dict(cnn_encoder="tf_efficientnetv2_m", effnet_depth_div=3)):
+        args = mini_args(**kw)
+        _, hip = build_pair(args, seed=6)
+        img, ids, seg, mask, tgt = (t.to(dev()) for t in synth.roco_batch(2, 12, 32, vocab=50, seed=4))
+        seen, snaps = [], []
+
+        def hook(lo, hi):
+            seen.append((lo, hi))
+            snaps.append((lo, hi, hip.flat_grads[lo:hi].clone()))   # stream-ordered copy at announcement time
+
+        hip.set_grad_ready_hook(hook)
+        hip.train()
+        mmvqa_amd.mlm_loss(hip(img, ids, seg, mask), tgt)[0].backward()
+        torch.cuda.synchronize()
+        n = hip.flat_grads.numel()
+        cover = sorted(seen)
+        assert cover[0][0] == 0 and cover[-1][1] == n and len(cover) >= 4
+        assert all(a[1] == b[0] for a, b in zip(cover[:-1], cover[1:])), cover
+        for lo, hi, snap in snaps:
+            assert torch.equal(snap, hip.flat_grads[lo:hi]), (lo, hi)
+        hip.set_grad_ready_hook(None)
