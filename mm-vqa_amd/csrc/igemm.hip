@@ -35,6 +35,7 @@ struct FastDiv {  // q = n / d for 0 <= n < 2^31 (host-computed magic; CUTLASS F
 };
 struct GemmAux {
   FastDiv ohw, ow;
+  int fast;   // 0: general loaders | 1: uniform-tap loaders | 2: uniform-tap loaders with a halo mask (host-decided)
 };
 
 __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
@@ -56,11 +57,46 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 #define MAX_TAPS 32
 
+// Phase timestamps of every workgroup (tools/igemm_trace.py builds the library with -DIGEMM_TRACE):
+// [wg][8] = {entry, loader state ready, first tile in LDS, K loop done, end} in s_memtime ticks (per-XCD counter),
+// HW_ID | XCC_ID << 32, entry and end in s_memrealtime ticks (100 MHz, chip-wide).
+#ifdef IGEMM_TRACE
+__device__ unsigned long long* g_igemm_trace = nullptr;
+extern "C" int mmvqa_debug_set_trace(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#define TRACE_MARK(i)                                                                              \
+  do {                                                                                             \
+    if (g_igemm_trace && threadIdx.x == 0) {                                                       \
+      unsigned long long* t_ = g_igemm_trace + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; \
+      t_[i] = __builtin_readcyclecounter();                                                        \
+      if ((i) == 0) {                                                                              \
+        t_[5] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |         \
+                ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32); \
+        t_[6] = __builtin_amdgcn_s_memrealtime();                                                  \
+      }                                                                                            \
+      if ((i) == 4) t_[7] = __builtin_amdgcn_s_memrealtime();                                      \
+    }                                                                                              \
+  } while (0)
+#define TRACE_STALL_DECL unsigned long long tr_vm = 0, tr_lgkm = 0, tr_bar = 0;
+#define TRACE_STALL_FLUSH()                                                                        \
+  do {                                                                                             \
+    if (g_igemm_trace && threadIdx.x == 0) {                                                       \
+      unsigned long long* t_ = g_igemm_trace + (1 << 22) + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4; \
+      t_[0] = tr_vm; t_[1] = tr_lgkm; t_[2] = tr_bar;                                              \
+    }                                                                                              \
+  } while (0)
+#else
+#define TRACE_MARK(i) do {} while (0)
+#define TRACE_STALL_DECL
+#define TRACE_STALL_FLUSH() do {} while (0)
+#endif
+
 // KS = intra-workgroup split of every K-tile over KS groups of 4 waves (KS*256 threads): for problems
 // with fewer workgroups than CUs it doubles the waves per SIMD (latency hiding) at the price of one
 // LDS reduction at the end.
 template <int BM, int BN, int BK, int KIND, bool NCHW, int KS>
-__global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, const GemmAux x) {
+__global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const GemmParams p, const GemmAux x) {
   constexpr int NT = 256 * KS;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int LDK = BK + 4;
@@ -78,6 +114,8 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
   constexpr int NAC = A_ROWK ? NA : NA_KM;   // chunks per thread actually used
   constexpr int NBC = B_ROWK ? NB : NB_KM;
 
+  TRACE_MARK(0);
+  TRACE_STALL_DECL
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][A_TILE]
   float* Bs = smem + 2 * A_TILE;    // [2][B_TILE]
@@ -88,6 +126,11 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+#ifdef EXP_SAMETILE   // experiment: every workgroup loads the tiles of workgroup (0,0) -> all loads hit in L2
+  const int lm0 = 0, ln0 = 0;
+#else
+  const int lm0 = m0, ln0 = n0;
+#endif
 
   // K range of this split
   const int nkt_total = (p.K + BK - 1) / BK;
@@ -127,7 +170,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
     }
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
-      const int row = m0 + a_r0 + RSTEP * r;
+      const int row = lm0 + a_r0 + RSTEP * r;
       a_base[r] = 0; a_mask[r] = 0; a_pix[r] = 0; a_y0[r] = -(1 << 24); a_x0[r] = -(1 << 24); a_img[r] = 0;
       if (row < p.M) {
         int n = row / OHW, rem = row - n * OHW;
@@ -160,7 +203,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
       }
     }
   } else {
-    const int i = m0 + akm_x4 * 4;
+    const int i = lm0 + akm_x4 * 4;
 #pragma unroll
     for (int r = 0; r < NA_KM; ++r) {
       a_base[r] = (k_begin + akm_k0 + A_KSTEP * r) * p.a_ld + i;   // advanced by BK*a_ld per K-tile
@@ -185,12 +228,12 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
   if constexpr (KIND == KIND_FWD) {
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      const int n = n0 + b_r0 + RSTEP * r;
+      const int n = ln0 + b_r0 + RSTEP * r;
       b_ok0[r] = n < p.N;
       b_base[r] = (n < p.N ? n : 0) * p.b_ld + b_kq + k_begin;   // advanced by BK per K-tile
     }
   } else if constexpr (KIND == KIND_DGRAD) {
-    const int n = n0 + bkm_x4 * 4;
+    const int n = ln0 + bkm_x4 * 4;
     b_colvalid = n < p.N;
 #pragma unroll
     for (int r = 0; r < NB_KM; ++r) {
@@ -200,7 +243,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
       b_base[r] = n; b_ok0[r] = 1;
     }
   } else {
-    const int nn = n0 + bkm_x4 * 4;
+    const int nn = ln0 + bkm_x4 * 4;
     b_colvalid = nn < p.N;
     if constexpr (!NCHW) {
       int tap = nn / p.g_Cs;
@@ -226,6 +269,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
     f32x4 ra[NAC], ra2[NAC], rb[NBC], rb2[NBC];
     uint32_t a_ok, b_ok;       // bit r: chunk r holds real data
     f32x4 ac0, ac1, ac2;      // A-prologue coefficients of this tile's channels
+    int tm[NAC];              // fast loaders: all-ones / zero halo mask of chunk r at this tile's tap
   };
 
   f32x16 acc[TM][TN];
@@ -242,91 +286,90 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
   // The whole K loop is instantiated per prologue mode so that its body is straight-line code
   // (loads -> MFMAs -> LDS writes in ONE basic block): the compiler can then slot the address
   // arithmetic and the prologue math between the 64-cycle MFMAs instead of running them serially.
-  auto run = [&](auto APRO_T, auto BPRO_T) __attribute__((always_inline)) {
+  auto run = [&](auto APRO_T, auto BPRO_T, auto FAST_T) __attribute__((always_inline)) {
     constexpr int APRO = decltype(APRO_T)::value;
     constexpr int BPRO = decltype(BPRO_T)::value;
+    constexpr int FAST = decltype(FAST_T)::value;
     constexpr bool A_TWO = (APRO == PRO_DZ);
     constexpr bool A_AFF = (APRO == PRO_AFFINE_RELU || APRO == PRO_AFFINE_SILU || APRO == PRO_SILU_GATE);
     constexpr bool B_AFF = (BPRO == PRO_AFFINE_RELU || BPRO == PRO_AFFINE_SILU || BPRO == PRO_SILU_GATE);
 
-    auto load_tile = [&](Stage& S, int kt) __attribute__((always_inline)) {
-      if constexpr (A_ROWK && !NCHW) {
-        const bool kvalid = a_tap < taps;
-        const int toff = taptab[kvalid ? a_tap : 0];
-        if constexpr (A_AFF || A_TWO) {
-          const int cc = kvalid ? a_c : 0;
-          S.ac0 = ld4(p.a_c0 + cc); S.ac1 = ld4(p.a_c1 + cc);
-          if constexpr (APRO == PRO_DZ) S.ac2 = ld4(p.a_c2 + cc);
+    // One K-tile of global loads, cut into NLP pieces (piece 0: per-tile scalars + prologue coefficients,
+    // then one piece per A chunk, then one per B chunk) so that the pipelined loop can place a piece behind
+    // every MFMA instead of a block of ~80 instructions behind one.
+    constexpr int NLP = 1 + NAC + NBC;
+    bool lt_kvalid = false;
+    int lt_toff = 0;
+    int lt_kh[4], lt_kw[4], lt_c[4];   // NCHW stem: tap decode of this thread's 4 k indices
+    auto load_piece = [&](Stage& S, int kt, int i) __attribute__((always_inline)) {
+      if (i == 0) {
+        S.a_ok = 0; S.b_ok = 0;
+        if constexpr (A_ROWK && !NCHW) {
+          lt_kvalid = a_tap < taps;
+          lt_toff = taptab[lt_kvalid ? a_tap : 0];
+          if constexpr (A_AFF || A_TWO) {
+            const int cc = lt_kvalid ? a_c : 0;
+            S.ac0 = ld4(p.a_c0 + cc); S.ac1 = ld4(p.a_c1 + cc);
+            if constexpr (APRO == PRO_DZ) S.ac2 = ld4(p.a_c2 + cc);
+          }
         }
-        S.a_ok = 0;
+        if constexpr (NCHW) {
+          S.a_ok = S.b_ok = ~0u;
+          if constexpr (A_ROWK) {
 #pragma unroll
-        for (int r = 0; r < NA; ++r) {
-          const bool ok = kvalid && ((a_mask[r] >> (a_tap & 31)) & 1u);
-          const int off = ok ? a_base[r] + toff + a_c : 0;
+            for (int j = 0; j < 4; ++j) {
+              const int kk = kt * BK + a_kq + j;
+              const int tap = kk / p.g_Cs;
+              lt_c[j] = kk - tap * p.g_Cs;
+              lt_kh[j] = tap / p.g_KW; lt_kw[j] = tap - lt_kh[j] * p.g_KW;
+              if (kk >= p.K) lt_kh[j] = -(1 << 24);
+            }
+          }
+        }
+      } else if (i <= NAC) {
+        const int r = i - 1;
+        if constexpr (A_ROWK && !NCHW) {
+          const bool ok = lt_kvalid && ((a_mask[r] >> (a_tap & 31)) & 1u);
+          const int off = ok ? a_base[r] + lt_toff + a_c : 0;
           S.ra[r] = ld4(p.A + off);
           if constexpr (A_TWO) S.ra2[r] = ld4(p.A2 + off);
           if constexpr (APRO == PRO_SILU_GATE) S.ra2[r] = ld4(p.gate + (ok ? a_img[r] * p.g_Cs + a_c : 0));
           S.a_ok |= (ok ? 1u : 0u) << r;
-        }
-        a_c += adv_c; a_tap += adv_tap;
-        const bool wrap = a_c >= p.g_Cs;
-        a_c = wrap ? a_c - p.g_Cs : a_c;
-        a_tap = wrap ? a_tap + 1 : a_tap;
-      } else if constexpr (A_ROWK && NCHW) {
-        // stem: NCHW source, scalar gather, K index = (kh*KW+kw)*Cs + c
-        const int k = kt * BK + a_kq;
-        int ekh[4], ekw[4], ec[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          int kk = k + j;
-          int tap = kk / p.g_Cs;
-          ec[j] = kk - tap * p.g_Cs;
-          ekh[j] = tap / p.g_KW; ekw[j] = tap - ekh[j] * p.g_KW;
-          if (kk >= p.K) ekh[j] = -(1 << 24);
-        }
-        S.a_ok = ~0u;
-#pragma unroll
-        for (int r = 0; r < NA; ++r) {
+          if (r == NAC - 1) {   // branch-free advance of (channel, tap) by one K-tile
+            a_c += adv_c; a_tap += adv_tap;
+            const bool wrap = a_c >= p.g_Cs;
+            a_c = wrap ? a_c - p.g_Cs : a_c;
+            a_tap = wrap ? a_tap + 1 : a_tap;
+          }
+        } else if constexpr (A_ROWK && NCHW) {
+          // stem: NCHW source, scalar gather, K index = (kh*KW+kw)*Cs + c
           f32x4 v = {0, 0, 0, 0};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            int sy = a_y0[r] + ekh[j], sx = a_x0[r] + ekw[j];
+            const int sy = a_y0[r] + lt_kh[j], sx = a_x0[r] + lt_kw[j];
             if (sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW)
-              v[j] = p.A[((size_t)(a_pix[r] * p.g_Cs + ec[j]) * p.g_SH + sy) * p.g_SW + sx];
+              v[j] = p.A[((size_t)(a_pix[r] * p.g_Cs + lt_c[j]) * p.g_SH + sy) * p.g_SW + sx];
           }
           S.ra[r] = v;
-        }
-      } else {
-        // WGRAD A': element (k = pixel, i = channel) at A[k*a_ld + i]
-        S.a_ok = 0;
-        const int kk0 = kt * BK + akm_k0;
-#pragma unroll
-        for (int r = 0; r < NA_KM; ++r) {
-          const bool ok = a_mask[r] && (kk0 + A_KSTEP * r < p.K);
+        } else {
+          // WGRAD A': element (k = pixel, i = channel) at A[k*a_ld + i]
+          const bool ok = a_mask[r] && (kt * BK + akm_k0 + A_KSTEP * r < p.K);
           const int off = ok ? a_base[r] : 0;
           S.ra[r] = ld4(p.A + off);
           if constexpr (A_TWO) S.ra2[r] = ld4(p.A2 + off);
           S.a_ok |= (ok ? 1u : 0u) << r;
           a_base[r] += BK * p.a_ld;
         }
-      }
-      // ---------------- B
-      if constexpr (KIND == KIND_FWD) {
-        const int k = kt * BK + b_kq;
-        S.b_ok = 0;
-        if constexpr (!NCHW) {
-          const bool kvalid = k < p.K;
-#pragma unroll
-          for (int r = 0; r < NB; ++r) {
-            const bool ok = kvalid && b_ok0[r];
+      } else {
+        const int r = i - 1 - NAC;
+        if constexpr (KIND == KIND_FWD) {
+          const int k = kt * BK + b_kq;
+          if constexpr (!NCHW) {
+            const bool ok = (k < p.K) && b_ok0[r];
             S.rb[r] = ld4(p.B + (ok ? b_base[r] : 0));
             S.b_ok |= (ok ? 1u : 0u) << r;
             b_base[r] += BK;
-          }
-        } else {
-          S.b_ok = ~0u;
-#pragma unroll
-          for (int r = 0; r < NB; ++r) {
+          } else {
             f32x4 v = {0, 0, 0, 0};
             if (b_ok0[r]) {
 #pragma unroll
@@ -335,11 +378,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
             S.rb[r] = v;
             b_base[r] += BK;
           }
-        }
-      } else if constexpr (KIND == KIND_DGRAD) {
-        S.b_ok = 0;
-#pragma unroll
-        for (int r = 0; r < NB_KM; ++r) {
+        } else if constexpr (KIND == KIND_DGRAD) {
           const bool ok = b_colvalid && (b_tap[r] < taps);
           const int off = ok ? b_co[r] * p.b_ld + b_tap[r] * p.b_tapstride + b_base[r] : 0;
           S.rb[r] = ld4(p.B + off);
@@ -348,11 +387,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
           const bool wrap = b_co[r] >= p.g_Cs;
           b_co[r] = wrap ? b_co[r] - p.g_Cs : b_co[r];
           b_tap[r] = wrap ? b_tap[r] + 1 : b_tap[r];
-        }
-      } else {
-        S.b_ok = 0;
-#pragma unroll
-        for (int r = 0; r < NB_KM; ++r) {
+        } else {
           const int m = b_base[r];
           b_base[r] += BK;
           const int n = fdiv(m, x.ohw), rem = m - n * OHW;
@@ -375,7 +410,6 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
               }
             }
             S.rb[r] = v;
-            S.b_ok = ~0u;
           }
         }
       }
@@ -438,6 +472,173 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
       }
     };
 
+
+    // ---------------------------------------------------------------- uniform-tap ("fast") loaders
+    // On gfx950 the fp32 MFMA shares the vector ALU: a VALU instruction of the same wave costs ~5 cycles of
+    // matrix-pipe time and nothing hides behind the MFMA except scalar and memory instructions
+    // (tools/mfma_coissue.hip).  The general loaders above spend ~160 VALU instructions per K-tile on
+    // addresses, masks and selects.  When a K-tile never straddles a filter tap (Cs % BK == 0) and nothing is
+    // ragged (host-checked), every per-thread byte offset is loop invariant and everything that changes from
+    // tile to tile is wave-uniform: it lives in SGPRs (scalar ALU, free) and reaches the load as the buffer
+    // instruction's soffset.  Rows / columns outside the matrix and halo taps use an offset beyond
+    // num_records: the hardware range check returns zeros without touching memory.
+    constexpr int BIG = (int)0x80000000;
+    __amdgpu_buffer_rsrc_t rA, rA2, rB, rC0, rC1, rC2;
+    int f_voffA[NAC], f_voffB[NBC];
+    const int f_voffC = a_kq * 4;
+    int f_tap = 0, f_c = 0, f_kh = 0, f_kw = 0;   // (tap, channel) of the next K-tile to load: wave-uniform
+    int f_runA = 0, f_runB = 0;                   // running byte offsets of the plain (non-gather) operands
+    int f_sA = 0, f_sB = 0, f_sC = 0;             // soffsets of the tile being loaded
+    const int f_sh = s - 1;                       // DGRAD: kh / stride as a shift (stride 1 or 2)
+    const int f_maxneg = (KIND == KIND_DGRAD) ? (((p.g_KH - 1) >> f_sh) * p.g_SW + ((p.g_KW - 1) >> f_sh)) * p.a_ld : 0;
+    auto bload = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) __attribute__((always_inline)) {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    if constexpr (FAST != 0) {
+      constexpr int FLAGS = 0x00020000;
+      constexpr int NREC = 0x7FFFF000;
+      if constexpr (A_ROWK) {
+        const int shift = (KIND == KIND_FWD) ? (p.g_pad * p.g_SW + p.g_pad) * p.a_ld : f_maxneg;
+        rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A - shift), 0, NREC, FLAGS);
+        rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)((A_TWO ? p.A2 : p.A) - shift), 0, NREC, FLAGS);
+        const int vshift = (KIND == KIND_FWD) ? shift : 0;
+#pragma unroll
+        for (int r = 0; r < NAC; ++r) {
+          const int off = (a_base[r] + vshift + a_kq) * 4;
+          f_voffA[r] = (FAST == 2 || (a_mask[r] & 1u)) ? off : BIG;
+        }
+        if constexpr (A_AFF || A_TWO) {
+          rC0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_c0, 0, p.g_Cs * 4, FLAGS);
+          rC1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_c1, 0, p.g_Cs * 4, FLAGS);
+          rC2 = __builtin_amdgcn_make_buffer_rsrc((void*)(APRO == PRO_DZ ? p.a_c2 : p.a_c1), 0, p.g_Cs * 4, FLAGS);
+        }
+        if (taps > 1) { f_tap = k_begin / p.g_Cs; f_c = k_begin - f_tap * p.g_Cs; } else { f_tap = 0; f_c = k_begin; }
+        f_kh = f_tap / p.g_KW; f_kw = f_tap - f_kh * p.g_KW;
+      } else {
+        rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.K * p.a_ld * 4, FLAGS);
+        rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(A_TWO ? p.A2 : p.A), 0, p.K * p.a_ld * 4, FLAGS);
+#pragma unroll
+        for (int r = 0; r < NAC; ++r) f_voffA[r] = a_mask[r] ? a_base[r] * 4 : BIG;
+      }
+      if constexpr (KIND == KIND_FWD) {
+        rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.N * p.b_ld * 4, FLAGS);
+#pragma unroll
+        for (int r = 0; r < NBC; ++r) f_voffB[r] = b_ok0[r] ? b_base[r] * 4 : BIG;
+      } else if constexpr (KIND == KIND_DGRAD) {
+        rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.g_Cs * p.b_ld * 4, FLAGS);
+#pragma unroll
+        for (int r = 0; r < NBC; ++r)
+          f_voffB[r] = b_colvalid ? ((bkm_k0 + B_KSTEP * r) * p.b_ld + b_base[r]) * 4 : BIG;
+      } else {
+        rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.K * p.b_ld * 4, FLAGS);
+#pragma unroll
+        for (int r = 0; r < NBC; ++r) f_voffB[r] = b_colvalid ? (b_base[r] * p.b_ld + b_ci) * 4 : BIG;
+      }
+    }
+    auto fload_piece = [&](Stage& S, int i) __attribute__((always_inline)) {
+      if (i == 0) {
+        if constexpr (A_ROWK) {
+          const bool live = f_tap < taps;
+          const int toff = (KIND == KIND_FWD) ? (f_kh * p.g_SW + f_kw) * p.a_ld
+                                              : f_maxneg - ((f_kh >> f_sh) * p.g_SW + (f_kw >> f_sh)) * p.a_ld;
+          f_sA = live ? (toff + f_c) * 4 : BIG;
+          f_sC = live ? f_c * 4 : BIG;
+          if constexpr (KIND == KIND_DGRAD) f_sB = live ? (f_c * p.b_ld + f_tap * p.b_tapstride) * 4 : BIG;
+          else f_sB = f_runB;
+          if constexpr (A_AFF || A_TWO) {
+            S.ac0 = bload(rC0, f_voffC, f_sC); S.ac1 = bload(rC1, f_voffC, f_sC);
+            if constexpr (APRO == PRO_DZ) S.ac2 = bload(rC2, f_voffC, f_sC);
+          }
+        } else {
+          f_sA = f_runA; f_sB = f_runB;
+        }
+      } else if (i <= NAC) {
+        const int r = i - 1;
+        int voff = f_voffA[r];
+        if constexpr (FAST == 2) {
+          const int t = __builtin_amdgcn_sbfe((int)a_mask[r], f_tap & 31, 1);
+          S.tm[r] = t;
+          voff = (t & voff) | (~t & BIG);
+        }
+        S.ra[r] = bload(rA, voff, f_sA);
+        if constexpr (A_TWO) S.ra2[r] = bload(rA2, voff, f_sA);
+      } else {
+        const int r = i - 1 - NAC;
+        S.rb[r] = bload(rB, f_voffB[r], f_sB);
+      }
+      if (i == NLP - 1) {   // advance the uniform position by one K-tile (scalar ALU)
+        if constexpr (A_ROWK) {
+          f_c += BK;
+          if (f_c >= p.g_Cs) {
+            f_c = 0; ++f_tap; ++f_kw;
+            if (f_kw == p.g_KW) { f_kw = 0; ++f_kh; }
+          }
+          f_runB += BK * 4;
+        } else {
+          f_runA += BK * p.a_ld * 4;
+          f_runB += BK * p.b_ld * 4;
+        }
+      }
+    };
+    auto fstore_chunk = [&](Stage& S, int buf, int c) __attribute__((always_inline)) {
+      float* as = As + buf * A_TILE;
+      float* bs = Bs + buf * B_TILE;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      if (c < NAC) {
+        const int r = c;
+        f32x4 v = S.ra[r];
+        if constexpr (APRO == PRO_AFFINE_RELU) {
+          const f32x2 lo = __builtin_elementwise_fma(v.xy, S.ac0.xy, S.ac1.xy), hi = __builtin_elementwise_fma(v.zw, S.ac0.zw, S.ac1.zw);
+          if constexpr (FAST == 2) {
+            const float lim = __builtin_bit_cast(float, S.tm[r] & 0x7f800000);   // +inf where the tap is inside the image, else 0
+            v[0] = __builtin_amdgcn_fmed3f(lo[0], 0.f, lim); v[1] = __builtin_amdgcn_fmed3f(lo[1], 0.f, lim);
+            v[2] = __builtin_amdgcn_fmed3f(hi[0], 0.f, lim); v[3] = __builtin_amdgcn_fmed3f(hi[1], 0.f, lim);
+          } else {
+            v[0] = fmaxf(lo[0], 0.f); v[1] = fmaxf(lo[1], 0.f); v[2] = fmaxf(hi[0], 0.f); v[3] = fmaxf(hi[1], 0.f);
+          }
+        } else if constexpr (APRO == PRO_DZ) {
+          const f32x4 z = S.ra2[r];
+          f32x2 lo = __builtin_elementwise_fma(z.xy, S.ac1.xy, S.ac2.xy), hi = __builtin_elementwise_fma(z.zw, S.ac1.zw, S.ac2.zw);
+          lo = __builtin_elementwise_fma(v.xy, S.ac0.xy, lo); hi = __builtin_elementwise_fma(v.zw, S.ac0.zw, hi);
+          v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+          if constexpr (FAST == 2) {   // halo taps: zero (the loads returned 0, the affine part did not)
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const int tmask = S.tm[r];
+            const i32x4 vi = __builtin_bit_cast(i32x4, v) & i32x4{tmask, tmask, tmask, tmask};
+            v = __builtin_bit_cast(f32x4, vi);
+          }
+        }
+        if constexpr (A_ROWK) {
+          *reinterpret_cast<f32x4*>(&as[(a_r0 + RSTEP * r) * LDK + a_kq]) = v;
+        } else {
+          *reinterpret_cast<f32x4*>(&as[(akm_k0 + A_KSTEP * r) * LDA_KM + akm_x4 * 4]) = v;
+        }
+      } else {
+        const int r = c - NAC;
+        f32x4 v = S.rb[r];
+        if constexpr (KIND == KIND_WGRAD && BPRO == PRO_AFFINE_RELU) {
+          const f32x2 lo = __builtin_elementwise_fma(v.xy, bc0.xy, bc1.xy), hi = __builtin_elementwise_fma(v.zw, bc0.zw, bc1.zw);
+          v[0] = fmaxf(lo[0], 0.f); v[1] = fmaxf(lo[1], 0.f); v[2] = fmaxf(hi[0], 0.f); v[3] = fmaxf(hi[1], 0.f);
+        }
+        if constexpr (B_ROWK) {
+          *reinterpret_cast<f32x4*>(&bs[(b_r0 + RSTEP * r) * LDK + b_kq]) = v;
+        } else {
+          *reinterpret_cast<f32x4*>(&bs[(bkm_k0 + B_KSTEP * r) * LDB_KM + bkm_x4 * 4]) = v;
+        }
+      }
+    };
+    // dispatch between the two loader families (compile-time per instantiation of run)
+    auto LP = [&](Stage& S, int kt, int i) __attribute__((always_inline)) {
+      if constexpr (FAST != 0) fload_piece(S, i); else load_piece(S, kt, i);
+    };
+    auto SC = [&](Stage& S, int buf, int kt, int c) __attribute__((always_inline)) {
+      if constexpr (FAST != 0) fstore_chunk(S, buf, c); else store_chunk(S, buf, kt, c);
+    };
+    auto LT = [&](Stage& S, int kt) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < NLP; ++i) LP(S, kt, i);
+    };
+
     auto read_frags = [&](const float* as, const float* bs, int kg, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -461,59 +662,105 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
 
     constexpr int NC = NAC + NBC;
     constexpr int NKG = BK / 8 / KS;                      // k-groups (8 deep) per wave per K-tile
-    constexpr int K0 = NKG / 2;                           // first k-group after which chunks are written
-    constexpr int PER = (NC + (NKG - K0) - 1) / (NKG - K0);
 
+    TRACE_MARK(1);
     Stage S0, S1;
     S0.a_ok = S0.b_ok = S1.a_ok = S1.b_ok = 0;
     S0.ac0 = S1.ac0 = ac0_i; S0.ac1 = S1.ac1 = ac1_i; S0.ac2 = S1.ac2 = ac2_i;
 
     if (nkt > 0) {
-      load_tile(S0, kt_begin);
+      LT(S0, kt_begin);
+      if constexpr (TM * TN == 1) LT(S1, kt_begin + 1);
 #pragma unroll
-      for (int c = 0; c < NC; ++c) store_chunk(S0, 0, kt_begin, c);
+      for (int c = 0; c < NC; ++c) SC(S0, 0, kt_begin, c);
     }
+    // No load may be pending across the loop entry: the wait-count pass merges the entry and the back-edge
+    // states, and a load still in flight here turns into a vmcnt(0) at the loop head of EVERY iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
+    TRACE_MARK(2);
 
     if constexpr (TM * TN == 1) {
-      // Software pipeline of the small tile (one barrier per K-tile, global loads TWO tiles ahead):
-      //   fragments of k-group kk+1 are read from LDS while the MFMAs of kk run;
-      //   the global loads of tile t+2 are issued behind the first MFMA group of tile t (address
-      //   arithmetic in the shadow of the matrix pipe) into the register stage that was drained one
-      //   iteration ago, so a load has a whole K-tile of MFMAs to arrive (measured: with one tile of
-      //   distance 35 % of the wave cycles were spent in s_waitcnt/barrier);
-      //   the LDS writes of tile t+1 (other buffer, last read one barrier ago) are spread over the second
-      //   half of the MFMA groups instead of forming a bubble before the barrier.
+      // Software pipeline of the small tile, one fenced slot per MFMA.  A wave's MFMAs form a dependent
+      // chain (one 32x32 accumulator), so the next one issues 64 cycles after its predecessor and ~15 VALU
+      // instructions fit in that shadow for free; anything clustered beyond that idles the matrix pipe.
+      // Left to itself the machine scheduler clusters: it sank the global loads to the end of the iteration
+      // (a vmcnt(0) at the loop head exposed the memory latency once per K-tile) and put the prologue math
+      // in a few long runs -- the round-1 phase trace showed the K loop at 2x its MFMA-only time.  So every
+      // slot is  MFMA ; one piece of side work ; sched_barrier:
+      //   slot 0 of each k-group : fragment read of the NEXT k-group (double-buffered registers);
+      //   slots L0..             : the global loads of tile t+2, one chunk per slot, into the register
+      //                            stage drained one iteration ago (two K-tiles of MFMAs to arrive);
+      //   slots ST0.. (stride)   : prologue math + LDS write of tile t+1, one chunk per slot;
+      //   last k-group           : its fragments are already in registers, so the barrier comes FIRST,
+      //                            then the fragment read of tile t+1's group 0, hidden by 4 MFMAs.
+      f32x4 fa[2][TM], fb[2][TN];
+      read_frags(As, Bs, ks, fa[0], fb[0]);
+      constexpr int NS = NKG * 4;                 // MFMA slots of one K-tile (one 32x32 tile per wave)
+      constexpr int SB = NS - 4;                  // the barrier sits in front of the last k-group
+      // A buffer_load_dwordx4 costs its wave ~25 cycles of texture-address time; the four waves of the
+      // workgroup run in lockstep, so loads issued in consecutive slots queue behind each other (measured:
+      // ~95 cycles per load per wave, 45 % of the MFMA time).  One load piece every LSTR-th slot keeps the
+      // address unit below ~50 % and the queue empty; the store chunks take the slots in between.
+      constexpr int L0 = 1;
+      constexpr int LSTR = (NS - 2) / NLP > 0 ? (NS - 2) / NLP : 1;
+      constexpr int ST0 = LSTR >= 2 ? L0 + 1 : L0 + NLP;
+      constexpr int STR = LSTR >= 2 ? LSTR : ((SB - ST0) / NC > 0 ? (SB - ST0) / NC : 1);
+      static_assert(ST0 + (NC - 1) * STR < SB, "load/store pieces do not fit in front of the barrier");
       auto body = [&](int t, Stage& Sload, Stage& Sstore) __attribute__((always_inline)) {
         const int buf = t & 1;
         const float* as = As + buf * A_TILE;
         const float* bs = Bs + buf * B_TILE;
-        f32x4 fa[2][TM], fb[2][TN];
-        read_frags(as, bs, ks, fa[0], fb[0]);
-#pragma unroll
-        for (int kk = 0; kk < NKG; ++kk) {
-          if (kk + 1 < NKG) read_frags(as, bs, (kk + 1) * KS + ks, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-              for (int b = 0; b < TN; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][a][j], fb[kk & 1][b][j], acc[a][b], 0, 0, 0);
-          if (kk == 0) load_tile(Sload, kt_begin + t + 2);   // unconditional: past the end everything is masked
-          if (kk >= K0) {
-#pragma unroll
-            for (int c = (kk - K0) * PER; c < (kk - K0 + 1) * PER && c < NC; ++c)
-              store_chunk(Sstore, buf ^ 1, kt_begin + t + 1, c);
+        static_for<NS>([&](auto SI) __attribute__((always_inline)) {
+          constexpr int sl = decltype(SI)::value, kk = sl / 4, j = sl % 4;
+          if constexpr (j == 0) {
+            if constexpr (kk + 1 < NKG) {
+              read_frags(as, bs, (kk + 1) * KS + ks, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+            } else {
+#ifdef IGEMM_TRACE
+              {
+                const unsigned long long ta = __builtin_readcyclecounter();
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+                const unsigned long long tb = __builtin_readcyclecounter();
+                __syncthreads();
+                const unsigned long long tc = __builtin_readcyclecounter();
+                tr_lgkm += tb - ta; tr_bar += tc - tb;
+              }
+#elif !defined(EXP_NOBAR)
+              __syncthreads();
+#endif
+              read_frags(As + (buf ^ 1) * A_TILE, Bs + (buf ^ 1) * B_TILE, ks, fa[0], fb[0]);
+            }
           }
-        }
-        __syncthreads();
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][0][j], fb[kk & 1][0][j], acc[0][0], 0, 0, 0);
+#ifndef EXP_NOLOAD
+          if constexpr (sl >= L0 && (sl - L0) % LSTR == 0 && (sl - L0) / LSTR < NLP)
+            LP(Sload, kt_begin + t + 2, (sl - L0) / LSTR);   // past the end everything is masked
+#endif
+#ifndef EXP_NOSTORE
+#ifdef IGEMM_TRACE
+          if constexpr (sl == ST0 && FAST != 0) {   // time the wait for the whole stage that is about to be written to LDS
+            constexpr int NLD = (A_ROWK && (A_AFF || A_TWO) ? (APRO == PRO_DZ ? 3 : 2) : 0) + NAC * (A_TWO ? 2 : 1) + NBC;
+            const unsigned long long ta = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (NLD & 15) | ((NLD >> 4) << 14));   // vmcnt(NLD): this body's own loads stay in flight
+            const unsigned long long tb = __builtin_readcyclecounter();
+            tr_vm += tb - ta;
+          }
+#endif
+          if constexpr (sl >= ST0 && sl < SB && (sl - ST0) % STR == 0 && (sl - ST0) / STR < NC)
+            SC(Sstore, buf ^ 1, kt_begin + t + 1, (sl - ST0) / STR);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        });
       };
-      if (nkt > 0) load_tile(S1, kt_begin + 1);
-      for (int t = 0; t < nkt; t += 2) {
+      // pairs only inside the loop (a conditional second half would add a head <- first-half path on which
+      // the first stage's loads are still in flight: the wait-count pass then drains everything at the head)
+      int t = 0;
+      for (; t + 1 < nkt; t += 2) {
         body(t, S0, S1);
-        if (t + 1 < nkt) body(t + 1, S1, S0);
+        body(t + 1, S1, S0);
       }
+      if (t < nkt) body(t, S0, S1);
     } else {
       // large wave tiles (16-64 MFMAs per k-group, two workgroups per CU): plain order, the second
       // resident workgroup covers the LDS-write/barrier bubble
@@ -521,7 +768,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
         const int buf = t & 1;
         const float* as = As + buf * A_TILE;
         const float* bs = Bs + buf * B_TILE;
-        load_tile(S0, kt_begin + t + 1);
+        LT(S0, kt_begin + t + 1);
 #pragma unroll
         for (int kk = 0; kk < NKG; ++kk) {
           f32x4 fa[TM], fb[TN];
@@ -535,7 +782,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
         }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) store_chunk(S0, buf ^ 1, kt_begin + t + 1, c);
+        for (int c = 0; c < NC; ++c) SC(S0, buf ^ 1, kt_begin + t + 1, c);
         __syncthreads();
       }
     }
@@ -547,31 +794,52 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
     using I2 = std::integral_constant<int, PRO_DZ>;
     using I4 = std::integral_constant<int, PRO_AFFINE_SILU>;
     using I5 = std::integral_constant<int, PRO_SILU_GATE>;
+    using G = std::integral_constant<int, 0>;    // general loaders
+    using F1 = std::integral_constant<int, 1>;   // uniform-tap loaders
+    using F2 = std::integral_constant<int, 2>;   // uniform-tap loaders + halo mask
     if constexpr (NCHW) {
-      if (KIND == KIND_WGRAD && p.a_pro == PRO_DZ) run(I2{}, I0{}); else run(I0{}, I0{});
+      if (KIND == KIND_WGRAD && p.a_pro == PRO_DZ) run(I2{}, I0{}, G{}); else run(I0{}, I0{}, G{});
     } else if constexpr (KIND == KIND_FWD) {
-      switch (p.a_pro) {
-        case PRO_AFFINE_RELU: run(I1{}, I0{}); break;
-        case PRO_AFFINE_SILU: run(I4{}, I0{}); break;
-        case PRO_SILU_GATE: run(I5{}, I0{}); break;
-        default: run(I0{}, I0{});
+      if (x.fast == 1) {
+        if (p.a_pro == PRO_AFFINE_RELU) run(I1{}, I0{}, F1{}); else run(I0{}, I0{}, F1{});
+      } else if (x.fast == 2) {
+        if (p.a_pro == PRO_AFFINE_RELU) run(I1{}, I0{}, F2{}); else run(I0{}, I0{}, F2{});
+      } else {
+        switch (p.a_pro) {
+          case PRO_AFFINE_RELU: run(I1{}, I0{}, G{}); break;
+          case PRO_AFFINE_SILU: run(I4{}, I0{}, G{}); break;
+          case PRO_SILU_GATE: run(I5{}, I0{}, G{}); break;
+          default: run(I0{}, I0{}, G{});
+        }
       }
     } else if constexpr (KIND == KIND_DGRAD) {
-      if (p.a_pro == PRO_DZ) run(I2{}, I0{}); else run(I0{}, I0{});
+      if (x.fast == 1) {
+        if (p.a_pro == PRO_DZ) run(I2{}, I0{}, F1{}); else run(I0{}, I0{}, F1{});
+      } else if (x.fast == 2) {
+        if (p.a_pro == PRO_DZ) run(I2{}, I0{}, F2{}); else run(I0{}, I0{}, F2{});
+      } else {
+        if (p.a_pro == PRO_DZ) run(I2{}, I0{}, G{}); else run(I0{}, I0{}, G{});
+      }
     } else {
-      if (p.a_pro == PRO_DZ) {
+      if (x.fast == 1) {
+        if (p.a_pro == PRO_DZ) {
+          if (p.b_pro == PRO_AFFINE_RELU) run(I2{}, I1{}, F1{}); else run(I2{}, I0{}, F1{});
+        } else {
+          if (p.b_pro == PRO_AFFINE_RELU) run(I0{}, I1{}, F1{}); else run(I0{}, I0{}, F1{});
+        }
+      } else if (p.a_pro == PRO_DZ) {
         switch (p.b_pro) {
-          case PRO_AFFINE_RELU: run(I2{}, I1{}); break;
-          case PRO_AFFINE_SILU: run(I2{}, I4{}); break;
-          case PRO_SILU_GATE: run(I2{}, I5{}); break;
-          default: run(I2{}, I0{});
+          case PRO_AFFINE_RELU: run(I2{}, I1{}, G{}); break;
+          case PRO_AFFINE_SILU: run(I2{}, I4{}, G{}); break;
+          case PRO_SILU_GATE: run(I2{}, I5{}, G{}); break;
+          default: run(I2{}, I0{}, G{});
         }
       } else {
         switch (p.b_pro) {
-          case PRO_AFFINE_RELU: run(I0{}, I1{}); break;
-          case PRO_AFFINE_SILU: run(I0{}, I4{}); break;
-          case PRO_SILU_GATE: run(I0{}, I5{}); break;
-          default: run(I0{}, I0{});
+          case PRO_AFFINE_RELU: run(I0{}, I1{}, G{}); break;
+          case PRO_AFFINE_SILU: run(I0{}, I4{}, G{}); break;
+          case PRO_SILU_GATE: run(I0{}, I5{}, G{}); break;
+          default: run(I0{}, I0{}, G{});
         }
       }
     }
@@ -583,6 +851,8 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
   // stores/loads whole 256-512 B row segments with 16-byte accesses (the per-lane dword pattern of the
   // MFMA layout reached only ~0.4 TB/s on the 616 MB tap maps), and every side tensor of the fused
   // epilogue (residual, ReLU-mask source, BatchNorm inputs, saved pre-activations) is read the same way.
+  TRACE_MARK(3);
+  TRACE_STALL_FLUSH();
   constexpr int LDC = BN + 4;
   constexpr int CH = BN / 4;            // float4 chunks per tile row
   constexpr int RP = NT / CH;           // rows per pass of the whole workgroup
@@ -639,6 +909,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
       const int row = m0 + rl, cc = n0 + cl;
       if (row < M && cc < N) atomicAdd(&C[(size_t)row * ldc + cc], ctile[rl * LDC + cl]);
     }
+    TRACE_MARK(4);
     return;
   }
 
@@ -683,6 +954,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
       const float v = lacc[i];
       if (v != 0.f && n0 + cl < N) atomicAdd(&out[(size_t)(img0 + sl) * N + n0 + cl], v);
     }
+    TRACE_MARK(4);
     return;
   }
 
@@ -703,6 +975,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
       for (int j = 0; j < 4; ++j) v[j] = g[j] * inv_hw * act_bwd(act, v[j]);
       stv(C, (size_t)row * ldc + col, v);
     }
+    TRACE_MARK(4);
     return;
   }
 
@@ -832,6 +1105,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_kernel(const GemmParams p, con
       }
     }
   }
+  TRACE_MARK(4);
 }
 
 // --------------------------------------------------------------------------- host launch
@@ -867,6 +1141,27 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
   GemmAux x;
   x.ohw = make_fastdiv(p.g_OH * p.g_OW);
   x.ow = make_fastdiv(p.g_OW);
+  // uniform-tap loaders: a K-tile never straddles a filter tap, nothing ragged, 31-bit byte offsets
+  x.fast = 0;
+  if (!NCHW && p.K % BK == 0 && !p.gate && !getenv("MMVQA_IGEMM_GENERAL")) {
+    const int taps = p.g_KH * p.g_KW;
+    const double lim = 2147483648.0 - 16777216.0;
+    if (KIND != KIND_WGRAD) {
+      const bool pro_ok = (KIND == KIND_FWD) ? (p.a_pro == PRO_NONE || p.a_pro == PRO_AFFINE_RELU)
+                                             : (p.a_pro == PRO_NONE || p.a_pro == PRO_DZ);
+      const double a_bytes = (KIND == KIND_FWD) ? (double)p.M * p.g_stride * p.g_stride * p.a_ld * 4.0 + (double)(p.g_SW + 2) * p.g_KH * p.a_ld * 4.0
+                                                : (double)p.M * p.a_ld * 4.0;
+      const double b_bytes = (KIND == KIND_FWD) ? (double)p.N * p.b_ld * 4.0 : (double)p.g_Cs * p.b_ld * 4.0;
+      if (pro_ok && p.b_pro == PRO_NONE && p.g_Cs % BK == 0 && p.g_stride <= 2 && a_bytes < lim && b_bytes < lim &&
+          (KIND == KIND_FWD || p.N % 4 == 0))
+        x.fast = (taps > 1 || (KIND == KIND_DGRAD && p.g_stride > 1)) ? 2 : 1;
+    } else {
+      const bool pro_ok = (p.a_pro == PRO_NONE || p.a_pro == PRO_DZ) && (p.b_pro == PRO_NONE || p.b_pro == PRO_AFFINE_RELU);
+      if (pro_ok && taps == 1 && p.g_stride == 1 && p.g_pad == 0 && p.M % 4 == 0 && p.N % 4 == 0 &&
+          (double)p.K * p.a_ld * 4.0 < lim && (double)p.K * p.b_ld * 4.0 < lim)
+        x.fast = 1;
+    }
+  }
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splitk);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, KIND, NCHW, KS>), grid, dim3(256 * KS), smem, stream, p, x);
   KERNEL_CHECK_RET();
