@@ -82,12 +82,18 @@ extern "C" int mmvqa_debug_set_trace(unsigned long long* buf) {
 #define TRACE_STALL_FLUSH()                                                                        \
   do {                                                                                             \
     if (g_igemm_trace && threadIdx.x == 0) {                                                       \
-      unsigned long long* t_ = g_igemm_trace + (1 << 22) + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4; \
+      unsigned long long* t_ = g_igemm_trace + (1 << 22) + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; \
       t_[0] = tr_vm; t_[1] = tr_lgkm; t_[2] = tr_bar;                                              \
     }                                                                                              \
   } while (0)
+#define TRACE_EPI(i)                                                                               \
+  do {                                                                                             \
+    if (g_igemm_trace && threadIdx.x == 0)                                                         \
+      g_igemm_trace[(1 << 22) + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + 4 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
 #else
 #define TRACE_MARK(i) do {} while (0)
+#define TRACE_EPI(i) do {} while (0)
 #define TRACE_STALL_DECL
 #define TRACE_STALL_FLUSH() do {} while (0)
 #endif
@@ -96,7 +102,7 @@ extern "C" int mmvqa_debug_set_trace(unsigned long long* buf) {
 // with fewer workgroups than CUs it doubles the waves per SIMD (latency hiding) at the price of one
 // LDS reduction at the end.
 template <int BM, int BN, int BK, int KIND, bool NCHW, int KS>
-__global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const GemmParams p, const GemmAux x) {
+__global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, const GemmAux x) {
   constexpr int NT = 256 * KS;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int LDK = BK + 4;
@@ -164,41 +170,54 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const 
   f32x4 ac0_i = {1, 1, 1, 1}, ac1_i = {0, 0, 0, 0}, ac2_i = {0, 0, 0, 0};   // WGRAD: loop-invariant A' coefficients
   const int akm_x4 = tid % A_X4, akm_k0 = tid / A_X4;
   if constexpr (A_ROWK) {
-    {
+    if (x.fast == 0) {   // per-thread (tap, channel) walk of the general loaders only
       int k = k_begin + a_kq;
       if (taps > 1) { a_tap = k / p.g_Cs; a_c = k - a_tap * p.g_Cs; } else { a_c = k; a_tap = (k >= p.g_Cs) ? 1 : 0; }
     }
+    // Row decode with the host-computed magic divisors, tap validity as (valid kh) x (valid kw): the
+    // straightforward per-tap loop with runtime divisions took 2.5-10 us per workgroup (phase trace).
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
       const int row = lm0 + a_r0 + RSTEP * r;
       a_base[r] = 0; a_mask[r] = 0; a_pix[r] = 0; a_y0[r] = -(1 << 24); a_x0[r] = -(1 << 24); a_img[r] = 0;
       if (row < p.M) {
-        int n = row / OHW, rem = row - n * OHW;
-        int oy = rem / p.g_OW, ox = rem - oy * p.g_OW;
-        a_img[r] = p.gate_hw > 0 ? row / p.gate_hw : 0;
+        const int n = fdiv(row, x.ohw), rem = row - n * OHW;
+        const int oy = fdiv(rem, x.ow), ox = rem - oy * p.g_OW;
+        if (p.gate_hw > 0) a_img[r] = row / p.gate_hw;
         if constexpr (NCHW) {
           a_pix[r] = n; a_y0[r] = oy * s - p.g_pad; a_x0[r] = ox * s - p.g_pad;
         } else if (KIND == KIND_FWD) {
-          int y0 = oy * s - p.g_pad, x0 = ox * s - p.g_pad;
+          const int y0 = oy * s - p.g_pad, x0 = ox * s - p.g_pad;
           a_base[r] = ((n * p.g_SH + y0) * p.g_SW + x0) * p.a_ld;
+          uint32_t xb = 0;
+          for (int kw = 0; kw < p.g_KW; ++kw) xb |= ((unsigned)(x0 + kw) < (unsigned)p.g_SW ? 1u : 0u) << kw;
           uint32_t mk = 0;
-          for (int t = 0; t < taps; ++t) {
-            int kh = t / p.g_KW, kw = t - kh * p.g_KW;
-            int sy = y0 + kh, sx = x0 + kw;
-            if (sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW) mk |= 1u << t;
-          }
+          for (int kh = 0; kh < p.g_KH; ++kh) mk |= ((unsigned)(y0 + kh) < (unsigned)p.g_SH ? xb : 0u) << (kh * p.g_KW);
           a_mask[r] = mk;
         } else {
-          int ty = oy + p.g_pad, tx = ox + p.g_pad;
-          int qy = ty / s, ry = ty - qy * s, qx = tx / s, rx = tx - qx * s;
-          a_base[r] = ((n * p.g_SH + qy) * p.g_SW + qx) * p.a_ld;
-          uint32_t mk = 0;
-          for (int t = 0; t < taps; ++t) {
-            int kh = t / p.g_KW, kw = t - kh * p.g_KW;
-            int sy = qy - kh / s, sx = qx - kw / s;
-            if ((kh % s) == ry && (kw % s) == rx && sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW) mk |= 1u << t;
+          const int ty = oy + p.g_pad, tx = ox + p.g_pad;
+          if (s <= 2) {
+            const int sh = s - 1, sm = s - 1;            // stride 1 or 2: divide / modulo as shift / and
+            const int qy = ty >> sh, ry = ty & sm, qx = tx >> sh, rx = tx & sm;
+            a_base[r] = ((n * p.g_SH + qy) * p.g_SW + qx) * p.a_ld;
+            uint32_t xb = 0;
+            for (int kw = 0; kw < p.g_KW; ++kw)
+              xb |= (((kw & sm) == rx && (unsigned)(qx - (kw >> sh)) < (unsigned)p.g_SW) ? 1u : 0u) << kw;
+            uint32_t mk = 0;
+            for (int kh = 0; kh < p.g_KH; ++kh)
+              mk |= (((kh & sm) == ry && (unsigned)(qy - (kh >> sh)) < (unsigned)p.g_SH) ? xb : 0u) << (kh * p.g_KW);
+            a_mask[r] = mk;
+          } else {
+            const int qy = ty / s, ry = ty - qy * s, qx = tx / s, rx = tx - qx * s;
+            a_base[r] = ((n * p.g_SH + qy) * p.g_SW + qx) * p.a_ld;
+            uint32_t mk = 0;
+            for (int t = 0; t < taps; ++t) {
+              const int kh = t / p.g_KW, kw = t - kh * p.g_KW;
+              const int sy = qy - kh / s, sx = qx - kw / s;
+              if ((kh % s) == ry && (kw % s) == rx && sy >= 0 && sy < p.g_SH && sx >= 0 && sx < p.g_SW) mk |= 1u << t;
+            }
+            a_mask[r] = mk;
           }
-          a_mask[r] = mk;
         }
       }
     }
@@ -238,17 +257,20 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const 
 #pragma unroll
     for (int r = 0; r < NB_KM; ++r) {
       int k = k_begin + bkm_k0 + B_KSTEP * r;
-      if (taps > 1) { b_tap[r] = k / p.g_Cs; b_co[r] = k - b_tap[r] * p.g_Cs; }
-      else { b_tap[r] = (k >= p.g_Cs) ? 1 : 0; b_co[r] = k; }
+      b_tap[r] = 0; b_co[r] = k;
+      if (x.fast == 0) {   // the uniform-tap loaders do not walk (tap, channel) per thread
+        if (taps > 1) { b_tap[r] = k / p.g_Cs; b_co[r] = k - b_tap[r] * p.g_Cs; }
+        else { b_tap[r] = (k >= p.g_Cs) ? 1 : 0; }
+      }
       b_base[r] = n; b_ok0[r] = 1;
     }
   } else {
     const int nn = ln0 + bkm_x4 * 4;
     b_colvalid = nn < p.N;
     if constexpr (!NCHW) {
-      int tap = nn / p.g_Cs;
+      int tap = 0;
+      if (taps > 1) { tap = nn / p.g_Cs; b_kh = tap / p.g_KW; b_kw = tap - b_kh * p.g_KW; }
       b_ci = nn - tap * p.g_Cs;
-      b_kh = tap / p.g_KW; b_kw = tap - b_kh * p.g_KW;
       if (p.b_pro != PRO_NONE && b_colvalid) { bc0 = ld4(p.b_c0 + b_ci); bc1 = ld4(p.b_c1 + b_ci); }
     } else {
 #pragma unroll
@@ -512,8 +534,10 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const 
           rC1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_c1, 0, p.g_Cs * 4, FLAGS);
           rC2 = __builtin_amdgcn_make_buffer_rsrc((void*)(APRO == PRO_DZ ? p.a_c2 : p.a_c1), 0, p.g_Cs * 4, FLAGS);
         }
-        if (taps > 1) { f_tap = k_begin / p.g_Cs; f_c = k_begin - f_tap * p.g_Cs; } else { f_tap = 0; f_c = k_begin; }
-        f_kh = f_tap / p.g_KW; f_kw = f_tap - f_kh * p.g_KW;
+        if (k_begin != 0) {
+          if (taps > 1) { f_tap = k_begin / p.g_Cs; f_c = k_begin - f_tap * p.g_Cs; } else { f_tap = 0; f_c = k_begin; }
+          f_kh = f_tap / p.g_KW; f_kw = f_tap - f_kh * p.g_KW;
+        }
       } else {
         rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.K * p.a_ld * 4, FLAGS);
         rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(A_TWO ? p.A2 : p.A), 0, p.K * p.a_ld * 4, FLAGS);
@@ -535,50 +559,66 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const 
         for (int r = 0; r < NBC; ++r) f_voffB[r] = b_colvalid ? (b_base[r] * p.b_ld + b_ci) * 4 : BIG;
       }
     }
-    auto fload_piece = [&](Stage& S, int i) __attribute__((always_inline)) {
-      if (i == 0) {
-        if constexpr (A_ROWK) {
-          const bool live = f_tap < taps;
-          const int toff = (KIND == KIND_FWD) ? (f_kh * p.g_SW + f_kw) * p.a_ld
-                                              : f_maxneg - ((f_kh >> f_sh) * p.g_SW + (f_kw >> f_sh)) * p.a_ld;
-          f_sA = live ? (toff + f_c) * 4 : BIG;
-          f_sC = live ? f_c * 4 : BIG;
-          if constexpr (KIND == KIND_DGRAD) f_sB = live ? (f_c * p.b_ld + f_tap * p.b_tapstride) * 4 : BIG;
-          else f_sB = f_runB;
-          if constexpr (A_AFF || A_TWO) {
-            S.ac0 = bload(rC0, f_voffC, f_sC); S.ac1 = bload(rC1, f_voffC, f_sC);
-            if constexpr (APRO == PRO_DZ) S.ac2 = bload(rC2, f_voffC, f_sC);
-          }
-        } else {
-          f_sA = f_runA; f_sB = f_runB;
-        }
-      } else if (i <= NAC) {
-        const int r = i - 1;
-        int voff = f_voffA[r];
-        if constexpr (FAST == 2) {
+    // One K-tile of fast loads in four steps, so that the pipelined loop can place them:
+    //   f_halo    (VALU, FAST == 2 only): per-chunk halo mask and effective offset for the tile at (f_tap, f_c);
+    //   f_scalars (SALU + the prologue-coefficient loads): soffsets of that tile;
+    //   f_chunk   (one buffer_load per call, two with the BatchNorm-backward operand);
+    //   f_advance (SALU): move (f_tap, f_c) to the next tile.
+    int f_ve[NAC];
+#pragma unroll
+    for (int r = 0; r < NAC; ++r) f_ve[r] = (FAST != 0) ? f_voffA[r] : 0;
+    auto f_halo = [&](Stage& S) __attribute__((always_inline)) {
+      if constexpr (FAST == 2) {
+#pragma unroll
+        for (int r = 0; r < NAC; ++r) {
           const int t = __builtin_amdgcn_sbfe((int)a_mask[r], f_tap & 31, 1);
           S.tm[r] = t;
-          voff = (t & voff) | (~t & BIG);
+          f_ve[r] = (t & f_voffA[r]) | (~t & BIG);
         }
-        S.ra[r] = bload(rA, voff, f_sA);
-        if constexpr (A_TWO) S.ra2[r] = bload(rA2, voff, f_sA);
+      }
+    };
+    auto f_scalars = [&](Stage& S) __attribute__((always_inline)) {
+      if constexpr (A_ROWK) {
+        const bool live = f_tap < taps;
+        const int toff = (KIND == KIND_FWD) ? (f_kh * p.g_SW + f_kw) * p.a_ld
+                                            : f_maxneg - ((f_kh >> f_sh) * p.g_SW + (f_kw >> f_sh)) * p.a_ld;
+        f_sA = live ? (toff + f_c) * 4 : BIG;
+        f_sC = live ? f_c * 4 : BIG;
+        if constexpr (KIND == KIND_DGRAD) f_sB = live ? (f_c * p.b_ld + f_tap * p.b_tapstride) * 4 : BIG;
+        else f_sB = f_runB;
+        if constexpr (A_AFF || A_TWO) {
+          S.ac0 = bload(rC0, f_voffC, f_sC); S.ac1 = bload(rC1, f_voffC, f_sC);
+          if constexpr (APRO == PRO_DZ) S.ac2 = bload(rC2, f_voffC, f_sC);
+        }
       } else {
-        const int r = i - 1 - NAC;
-        S.rb[r] = bload(rB, f_voffB[r], f_sB);
+        f_sA = f_runA; f_sB = f_runB;
       }
-      if (i == NLP - 1) {   // advance the uniform position by one K-tile (scalar ALU)
-        if constexpr (A_ROWK) {
-          f_c += BK;
-          if (f_c >= p.g_Cs) {
-            f_c = 0; ++f_tap; ++f_kw;
-            if (f_kw == p.g_KW) { f_kw = 0; ++f_kh; }
-          }
-          f_runB += BK * 4;
-        } else {
-          f_runA += BK * p.a_ld * 4;
-          f_runB += BK * p.b_ld * 4;
+    };
+    auto f_chunk = [&](Stage& S, int i) __attribute__((always_inline)) {
+      if (i < NAC) {
+        S.ra[i] = bload(rA, f_ve[i], f_sA);
+        if constexpr (A_TWO) S.ra2[i] = bload(rA2, f_ve[i], f_sA);
+      } else {
+        S.rb[i - NAC] = bload(rB, f_voffB[i - NAC], f_sB);
+      }
+    };
+    auto f_advance = [&]() __attribute__((always_inline)) {
+      if constexpr (A_ROWK) {
+        f_c += BK;
+        if (f_c >= p.g_Cs) {
+          f_c = 0; ++f_tap; ++f_kw;
+          if (f_kw == p.g_KW) { f_kw = 0; ++f_kh; }
         }
+        f_runB += BK * 4;
+      } else {
+        f_runA += BK * p.a_ld * 4;
+        f_runB += BK * p.b_ld * 4;
       }
+    };
+    auto fload_piece = [&](Stage& S, int i) __attribute__((always_inline)) {   // piece view used by LT
+      if (i == 0) { f_halo(S); f_scalars(S); }
+      else f_chunk(S, i - 1);
+      if (i == NLP - 1) f_advance();
     };
     auto fstore_chunk = [&](Stage& S, int buf, int c) __attribute__((always_inline)) {
       float* as = As + buf * A_TILE;
@@ -673,6 +713,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const 
       if constexpr (TM * TN == 1) LT(S1, kt_begin + 1);
 #pragma unroll
       for (int c = 0; c < NC; ++c) SC(S0, 0, kt_begin, c);
+      if constexpr (FAST != 0 && TM * TN == 1) f_halo(S0);   // S0 receives tile kt_begin + 2 next
     }
     // No load may be pending across the loop entry: the wait-count pass merges the entry and the back-edge
     // states, and a load still in flight here turns into a vmcnt(0) at the loop head of EVERY iteration.
@@ -707,6 +748,9 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const 
       constexpr int ST0 = LSTR >= 2 ? L0 + 1 : L0 + NLP;
       constexpr int STR = LSTR >= 2 ? LSTR : ((SB - ST0) / NC > 0 ? (SB - ST0) / NC : 1);
       static_assert(ST0 + (NC - 1) * STR < SB, "load/store pieces do not fit in front of the barrier");
+      constexpr int SV = SB - (NS >= 32 ? 5 : 3);   // fast loaders: the slot of the single VALU block (its LDS writes land before the barrier)
+      constexpr int FLS = (SV - 2) / NC > 0 ? (SV - 2) / NC : 1;
+      static_assert(2 + (NC - 1) * FLS < SV, "fast load slots must precede the VALU slot");
       auto body = [&](int t, Stage& Sload, Stage& Sstore) __attribute__((always_inline)) {
         const int buf = t & 1;
         const float* as = As + buf * A_TILE;
@@ -734,12 +778,18 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const 
           }
           acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][0][j], fb[kk & 1][0][j], acc[0][0], 0, 0, 0);
 #ifndef EXP_NOLOAD
-          if constexpr (sl >= L0 && (sl - L0) % LSTR == 0 && (sl - L0) / LSTR < NLP)
-            LP(Sload, kt_begin + t + 2, (sl - L0) / LSTR);   // past the end everything is masked
+          if constexpr (FAST != 0) {
+            // scalars in slot 1, then one buffer_load every FLS-th slot, all issued before the VALU slot SV
+            if constexpr (sl == 1) f_scalars(Sload);
+            if constexpr (sl >= 2 && sl < SV && (sl - 2) % FLS == 0 && (sl - 2) / FLS < NC) f_chunk(Sload, (sl - 2) / FLS);
+          } else {
+            if constexpr (sl >= L0 && (sl - L0) % LSTR == 0 && (sl - L0) / LSTR < NLP)
+              LP(Sload, kt_begin + t + 2, (sl - L0) / LSTR);   // past the end everything is masked
+          }
 #endif
 #ifndef EXP_NOSTORE
 #ifdef IGEMM_TRACE
-          if constexpr (sl == ST0 && FAST != 0) {   // time the wait for the whole stage that is about to be written to LDS
+          if constexpr (sl == SV && FAST != 0) {   // time the wait for the whole stage that is about to be written to LDS
             constexpr int NLD = (A_ROWK && (A_AFF || A_TWO) ? (APRO == PRO_DZ ? 3 : 2) : 0) + NAC * (A_TWO ? 2 : 1) + NBC;
             const unsigned long long ta = __builtin_readcyclecounter();
             __builtin_amdgcn_s_waitcnt(0x0F70 | (NLD & 15) | ((NLD >> 4) << 14));   // vmcnt(NLD): this body's own loads stay in flight
@@ -747,8 +797,20 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const 
             tr_vm += tb - ta;
           }
 #endif
-          if constexpr (sl >= ST0 && sl < SB && (sl - ST0) % STR == 0 && (sl - ST0) / STR < NC)
-            SC(Sstore, buf ^ 1, kt_begin + t + 1, (sl - ST0) / STR);
+          if constexpr (FAST != 0) {
+            // ONE vector-ALU block per K-tile (a VALU instruction costs ~4 cycles inside a run but ~10 when
+            // sprinkled between MFMAs: tools/mfma_tile_budget.hip): the prologue math + LDS writes of tile t+1,
+            // then the position advance and the halo masks of the tile this register stage receives next
+            if constexpr (sl == SV) {
+#pragma unroll
+              for (int c = 0; c < NC; ++c) fstore_chunk(Sstore, buf ^ 1, c);
+              f_advance();
+              f_halo(Sstore);
+            }
+          } else {
+            if constexpr (sl >= ST0 && sl < SB && (sl - ST0) % STR == 0 && (sl - ST0) / STR < NC)
+              SC(Sstore, buf ^ 1, kt_begin + t + 1, (sl - ST0) / STR);
+          }
 #endif
           __builtin_amdgcn_sched_barrier(0);
         });
@@ -877,6 +939,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const 
     __syncthreads();
   }
 
+  TRACE_EPI(0);
   const int M = p.M, N = p.N;
   const int c4 = tid % CH, rg = tid / CH;
   const int col = n0 + c4 * 4;
@@ -1000,108 +1063,123 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 4 : 2) void igemm_kernel(const 
       if (st1 && stat_bwd) { mu1 = ldv(p.mean1, col); is1 = ldv(p.invstd1, col); }
       if (st2) { mu2 = ldv(p.mean2, col); is2 = ldv(p.invstd2, col); }
     }
-    double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0}, sc[4] = {0, 0, 0, 0};
-    f32x4 cs = {0, 0, 0, 0};
+    // Per-thread partial sums stay in fp32 (at most BM/RP rows each); they are widened to fp64 when they
+    // meet the other row groups.  The passes run in blocks of UP with every side-tensor load of a block
+    // issued before its first use: one pass at a time paid a full memory latency per pass (phase trace:
+    // 3 us for the 4 passes of a 64x64 tile).
+    f32x4 sa = {0, 0, 0, 0}, sb = {0, 0, 0, 0}, sc = {0, 0, 0, 0}, cs = {0, 0, 0, 0};
+    TRACE_EPI(3);
+    constexpr int UP = NPASS < 4 ? NPASS : 4;
 #pragma unroll 1
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int rl = rg + ps * RP, row = m0 + rl;
-      if (row >= M || !cok) break;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[rl * LDC + c4 * 4]);
-      v += bias;
-      if (Cpre) stv(Cpre, (size_t)row * ldc + col, v);
-      if (dact) {
-        const f32x4 pr = ldv(Pre, (size_t)row * pre_ld + col);
+    for (int ps0 = 0; ps0 < NPASS; ps0 += UP) {
+      if (m0 + rg + ps0 * RP >= M || !cok) break;
+      f32x4 vv[UP], pr[UP], rr[UP], mm[UP], zz[UP], zz2[UP];
+      bool ok[UP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= act_bwd(dact, pr[j]);
-      }
-      if (act) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_fwd(act, v[j]);
-      }
-      if (drop_p > 0.f) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float u = rng_uniform(drop_seed, (uint32_t)row * (uint32_t)N + (uint32_t)(col + j));
-          v[j] = (u >= drop_p) ? v[j] * keep_scale : 0.f;
+      for (int u = 0; u < UP; ++u) {
+        const int rl = rg + (ps0 + u) * RP, row = m0 + rl;
+        ok[u] = row < M;
+        const size_t rw = ok[u] ? (size_t)row : (size_t)m0;   // clamped: loads of a row past the end are discarded
+        vv[u] = *reinterpret_cast<const f32x4*>(&ctile[rl * LDC + c4 * 4]);
+        if (dact) pr[u] = ldv(Pre, rw * pre_ld + col);
+        if (R) rr[u] = ldv(R, rw * r_ld + col);
+        if (Mk) mm[u] = ldv(Mk, rw * mk_ld + col);
+        if (st1 && stat_bwd) {
+          zz[u] = ldv(Z1, rw * z1_ld + col);
+          if (st2) zz2[u] = ldv(Z2, rw * z2_ld + col);
         }
       }
-      if (R) v += ldv(R, (size_t)row * r_ld + col);
-      if (Mk) {
-        const f32x4 m = ldv(Mk, (size_t)row * mk_ld + col);
-        if (mk_mode == 0) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (m[j] * mks[j] + mkb[j] > 0.f) ? v[j] : 0.f;
-        } else {
+      for (int u = 0; u < UP; ++u) {
+        if (!ok[u]) continue;
+        const int row = m0 + rg + (ps0 + u) * RP;
+        f32x4 v = vv[u] + bias;
+        if (Cpre) stv(Cpre, (size_t)row * ldc + col, v);
+        if (dact) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] *= dsilu_f(m[j] * mks[j] + mkb[j]);
+          for (int j = 0; j < 4; ++j) v[j] *= act_bwd(dact, pr[u][j]);
         }
-      }
-      stv(C, (size_t)row * ldc + col, v);
-      if (st1) {
-        if (stat_bwd) {
-          const f32x4 z = ldv(Z1, (size_t)row * z1_ld + col);
+        if (act) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { sa[j] += (double)v[j]; sb[j] += (double)(v[j] * ((z[j] - mu1[j]) * is1[j])); }
-          if (st2) {
-            const f32x4 z2 = ldv(Z2, (size_t)row * z2_ld + col);
+          for (int j = 0; j < 4; ++j) v[j] = act_fwd(act, v[j]);
+        }
+        if (drop_p > 0.f) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sc[j] += (double)(v[j] * ((z2[j] - mu2[j]) * is2[j]));
+          for (int j = 0; j < 4; ++j) {
+            const float uu = rng_uniform(drop_seed, (uint32_t)row * (uint32_t)N + (uint32_t)(col + j));
+            v[j] = (uu >= drop_p) ? v[j] * keep_scale : 0.f;
           }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { sa[j] += (double)v[j]; sb[j] += (double)v[j] * (double)v[j]; }
         }
+        if (R) v += rr[u];
+        if (Mk) {
+          if (mk_mode == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (mm[u][j] * mks[j] + mkb[j] > 0.f) ? v[j] : 0.f;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= dsilu_f(mm[u][j] * mks[j] + mkb[j]);
+          }
+        }
+#ifndef EXP_NOSTOREC
+        stv(C, (size_t)row * ldc + col, v);
+#endif
+        if (st1) {
+          if (stat_bwd) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sa[j] += v[j]; sb[j] += v[j] * ((zz[u][j] - mu1[j]) * is1[j]); }
+            if (st2) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sc[j] += v[j] * ((zz2[u][j] - mu2[j]) * is2[j]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sa[j] += v[j]; sb[j] += v[j] * v[j]; }
+          }
+        }
+        if (colsum) cs += v;
       }
-      if (colsum) cs += v;
     }
+    TRACE_EPI(1);
     if (st1 || colsum) {
-      // reduce the RP row groups of the workgroup through LDS, then ONE atomic per column
+      // combine the RP row groups of the workgroup with LDS atomics (fp64 for the statistics), then ONE global
+      // atomic per column and statistic
       __syncthreads();                       // everyone is done reading ctile
-      double* red = reinterpret_cast<double*>(smem);   // [RP][BN][3]
-      float* redf = smem;                               // [RP][BN] (colsum only)
-      if (st1) {
+      double* red = reinterpret_cast<double*>(smem);   // [BN][3]
+      float* redf = smem + BN * 6;                      // [BN]
+      for (int i = tid; i < BN * 3; i += NT) red[i] = 0.0;
+      for (int i = tid; i < BN; i += NT) redf[i] = 0.f;
+      __syncthreads();
+      if (cok) {
+        if (st1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          double* d = red + ((size_t)rg * BN + c4 * 4 + j) * 3;
-          d[0] = sa[j]; d[1] = sb[j]; d[2] = sc[j];
+          for (int j = 0; j < 4; ++j) {
+            double* d = red + (c4 * 4 + j) * 3;
+            atomicAdd(d, (double)sa[j]);
+            atomicAdd(d + 1, (double)sb[j]);
+            if (st2) atomicAdd(d + 2, (double)sc[j]);
+          }
         }
-      } else {
+        if (colsum) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) redf[rg * BN + c4 * 4 + j] = cs[j];
+          for (int j = 0; j < 4; ++j) atomicAdd(&redf[c4 * 4 + j], cs[j]);
+        }
       }
       __syncthreads();
+      TRACE_EPI(2);
       if (tid < BN && n0 + tid < N) {
         if (st1) {
-          double a0 = 0, a1 = 0, a2 = 0;
-          for (int g = 0; g < RP; ++g) {
-            const double* d = red + ((size_t)g * BN + tid) * 3;
-            a0 += d[0]; a1 += d[1]; a2 += d[2];
-          }
+          const double* d = red + tid * 3;
           const int slot = (blockIdx.y + blockIdx.x * 7 + blockIdx.z * 3) & (MMVQA_STAT_SLOTS - 1);
           double* d1 = st1 + ((size_t)slot * N + n0 + tid) * 2;
-          atomicAdd(d1, a0);
-          atomicAdd(d1 + 1, a1);
+          atomicAdd(d1, d[0]);
+          atomicAdd(d1 + 1, d[1]);
           if (st2) {
             double* d2 = st2 + ((size_t)slot * N + n0 + tid) * 2;
-            atomicAdd(d2, a0);
-            atomicAdd(d2 + 1, a2);
+            atomicAdd(d2, d[0]);
+            atomicAdd(d2 + 1, d[2]);
           }
-        } else {
-          float a0 = 0.f;
-          for (int g = 0; g < RP; ++g) a0 += redf[g * BN + tid];
-          atomicAdd(&colsum[n0 + tid], a0);
         }
-      }
-      if (st1 && colsum) {   // both requested (not used by the engine): second round for the float sums
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) redf[rg * BN + c4 * 4 + j] = cs[j];
-        __syncthreads();
-        if (tid < BN && n0 + tid < N) {
-          float a0 = 0.f;
-          for (int g = 0; g < RP; ++g) a0 += redf[g * BN + tid];
-          atomicAdd(&colsum[n0 + tid], a0);
-        }
+        if (colsum) atomicAdd(&colsum[n0 + tid], redf[tid]);
       }
     }
   }

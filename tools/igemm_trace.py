@@ -87,7 +87,7 @@ def main():
                 torch.cuda.synchronize()
                 tall = trace.cpu().numpy()
                 t = tall[:1 << 22].reshape(-1, 8)
-                stl = tall[1 << 22:].reshape(-1, 4)
+                stl = tall[1 << 22:].reshape(-1, 8)
                 sel = t[:, 0] != 0
                 stl = stl[:int(sel.sum())]
                 t = t[sel]
@@ -108,7 +108,9 @@ def main():
                       f"start p50/p90/max {st[nwg // 2]:5.1f}/{st[int(nwg * .9)]:5.1f}/{st[-1]:5.1f}  "
                       f"phases setup {ph[0]:5.2f} first {ph[1]:5.2f} loop {ph[2]:5.2f} epi {ph[3]:5.2f}  "
                       f"life mean {life.mean():5.1f} max {life.max():5.1f}  span {span:5.1f} us  CUs {ncu}  MHz {1 / tick:5.0f}  "
-                      f"stall vm {stl[:, 0].mean() * tick:5.2f} lgkm {stl[:, 1].mean() * tick:5.2f} bar {stl[:, 2].mean() * tick:5.2f}", flush=True)
+                      f"stall vm {stl[:, 0].mean() * tick:5.2f} lgkm {stl[:, 1].mean() * tick:5.2f} bar {stl[:, 2].mean() * tick:5.2f}  "
+                      f"epi: stage {(stl[:, 4] - t[:, 3]).mean() * tick:5.2f} pre {(stl[:, 7] - stl[:, 4]).mean() * tick:5.2f} passes {(stl[:, 5] - stl[:, 7]).mean() * tick:5.2f} "
+                      f"red {(stl[:, 6] - stl[:, 5]).mean() * tick:5.2f} final {(t[:, 4] - stl[:, 6]).mean() * tick:5.2f}", flush=True)
 
 
 if __name__ == "__main__":
