@@ -94,6 +94,8 @@ typedef struct mmvqa_gemm_desc {
   const float* gate; /* PRO_SILU_GATE: [image][g_Cs] squeeze-excite gates; image = pixel / gate_hw */
   int gate_hw;
   int mk_mode;       /* 0: ReLU mask (Mk*s+b > 0), 1: multiply by SiLU'(Mk*s+b) */
+  const int* pixmask; /* optional, KIND_WGRAD of a stride-1 "same" convolution: per output pixel the bit mask of filter
+                         taps that fall inside the image (mmvqa_pixmask); enables the uniform-tap weight-gradient loaders */
 } mmvqa_gemm_desc;
 
 /* Fused attention (models/transformer.py:19-30 and models/realformer.py:30-45). */
@@ -212,6 +214,11 @@ int mmvqa_adam(mmvqa_stream_t s, float* p, float* g, float* m, float* v, long n,
 int mmvqa_axpy(mmvqa_stream_t s, float* y, const float* x, float a, long n);
 int mmvqa_colsum(mmvqa_stream_t s, const float* x, int ld, int rows, int cols, float* out);
 int mmvqa_dropout(mmvqa_stream_t s, float* x, long n, float p, uint32_t seed);
+/* out[n*OH*OW + oy*OW + ox] = bit (kh*KW + kw) set iff input pixel (oy*stride - pad + kh, ox*stride - pad + kw) lies
+ * inside the SH x SW image: the zero-padding pattern of torch.nn.Conv2d (torchvision Bottleneck.conv2), as consumed
+ * by mmvqa_gemm_desc.pixmask */
+int mmvqa_pixmask(mmvqa_stream_t s, int* out, int N, int OH, int OW, int SH, int SW, int KH, int KW, int stride,
+                  int pad);
 
 /* ---- engine level: the whole Model.forward / backward (models/mmbert.py:150-167) ------------ */
 int mmvqa_engine_create(const mmvqa_model_desc* desc, mmvqa_engine** out);

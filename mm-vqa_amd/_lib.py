@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
         ("stat1", c_ptr), ("stat_bwd", C.c_int), ("Z1", c_ptr), ("z1_ld", C.c_int), ("mean1", c_ptr),
         ("invstd1", c_ptr),
         ("stat2", c_ptr), ("Z2", c_ptr), ("z2_ld", C.c_int), ("mean2", c_ptr), ("invstd2", c_ptr),
-        ("colsum", c_ptr), ("gate", c_ptr), ("gate_hw", C.c_int), ("mk_mode", C.c_int),
+        ("colsum", c_ptr), ("gate", c_ptr), ("gate_hw", C.c_int), ("mk_mode", C.c_int), ("pixmask", c_ptr),
     ]
 
 
@@ -98,6 +98,7 @@ SIGNATURES = {
     "mmvqa_axpy": (_i, [_P, _P, _P, _f, _l]),
     "mmvqa_colsum": (_i, [_P, _P, _i, _i, _i, _P]),
     "mmvqa_dropout": (_i, [_P, _P, _l, _f, _u32]),
+    "mmvqa_pixmask": (_i, [_P, _P] + [_i] * 9),
     "mmvqa_engine_create": (_i, [C.POINTER(ModelDesc), C.POINTER(_P)]),
     "mmvqa_engine_destroy": (None, [_P]),
     "mmvqa_engine_num_tensors": (_i, [_P]),

@@ -147,12 +147,19 @@ int mmvqa_dropout(mmvqa_stream_t s, float* x, long n, float p, uint32_t seed) {
   return k_dropout(ST(s), x, n, p, seed);
 }
 
+int mmvqa_pixmask(mmvqa_stream_t s, int* out, int N, int OH, int OW, int SH, int SW, int KH, int KW, int stride,
+                  int pad) {
+  if (!out) return mmvqa_set_error(MMVQA_ERR_ARG, "pixmask: null output");
+  return k_pixmask(ST(s), out, N, OH, OW, SH, SW, KH, KW, stride, pad);
+}
+
 // ---------------------------------------------------------------------------------- engine
 int mmvqa_engine_create(const mmvqa_model_desc* desc, mmvqa_engine** out) { return engine_create(desc, out); }
 void mmvqa_engine_destroy(mmvqa_engine* e) {
   if (!e) return;
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->side) (void)hipStreamDestroy(e->side);
+  for (auto& kv : e->pixmasks) (void)hipFree(kv.second);
   delete e;
 }
 int mmvqa_engine_num_tensors(const mmvqa_engine* e) { return e ? (int)e->specs.size() : 0; }

@@ -937,6 +937,28 @@ int k_dropout(hipStream_t st, float* x, long n, float p, uint32_t seed) {
   return MMVQA_OK;
 }
 
+// per output pixel: which filter taps read inside the image (the padding pattern of nn.Conv2d)
+__global__ void pixmask_kernel(int* out, int total, int OH, int OW, int SH, int SW, int KH, int KW, int stride, int pad) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= total) return;
+  const int rem = m % (OH * OW), oy = rem / OW, ox = rem - oy * OW;
+  const int y0 = oy * stride - pad, x0 = ox * stride - pad;
+  unsigned mk = 0;
+  for (int kh = 0; kh < KH; ++kh)
+    for (int kw = 0; kw < KW; ++kw)
+      if ((unsigned)(y0 + kh) < (unsigned)SH && (unsigned)(x0 + kw) < (unsigned)SW) mk |= 1u << (kh * KW + kw);
+  out[m] = (int)mk;
+}
+
+int k_pixmask(hipStream_t st, int* out, int N, int OH, int OW, int SH, int SW, int KH, int KW, int stride, int pad) {
+  if (KH * KW > 32) return mmvqa_set_error(MMVQA_ERR_ARG, "pixmask: at most 32 taps");
+  const int total = N * OH * OW;
+  if (total <= 0) return MMVQA_OK;
+  hipLaunchKernelGGL(pixmask_kernel, dim3((total + 255) / 256), dim3(256), 0, st, out, total, OH, OW, SH, SW, KH, KW, stride, pad);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
 int k_dropout_copy(hipStream_t st, const float* x, float* y, long n, float p, uint32_t seed) {
   hipLaunchKernelGGL(dropout_copy_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n, p, seed);
   KERNEL_CHECK_RET();

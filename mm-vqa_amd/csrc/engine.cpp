@@ -584,6 +584,19 @@ static int conv_wgrad(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const f
   g.g_SH = H; g.g_SW = W; g.g_Cs = c.Cin; g.g_OH = OH; g.g_OW = OW;
   conv_geom(g, c, H, W, OH, OW);
   g.C = GRD(c.w); g.c_ld = g.N; g.c_atomic = 1;
+  if (c.KH > 1 && c.stride == 1 && OH == H && OW == W) {
+    // stride-1 "same" convolution: hand the kernel the per-pixel tap-validity table (one per geometry)
+    char key[96];
+    snprintf(key, sizeof(key), "%d,%d,%d,%d,%d", N, OH, OW, c.KH, c.pad);
+    auto it = e->pixmasks.find(key);
+    if (it == e->pixmasks.end()) {
+      int* tab = nullptr;
+      HIP_CHECK_RET(hipMalloc(&tab, sizeof(int) * (size_t)N * OH * OW));
+      it = e->pixmasks.emplace(key, tab).first;
+      TRY(k_pixmask(st, tab, N, OH, OW, H, W, c.KH, c.KH, c.stride, c.pad));
+    }
+    g.pixmask = it->second;
+  }
   RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_WGRAD, 0, 0, st));
   return MMVQA_OK;
 }

@@ -1,6 +1,7 @@
 // Host runtime of the MMBERT hot path: parameter table, workspace plan and the launch sequences of
 // Model.forward / backward (models/mmbert.py:129-167).  Pure C++ over the HIP launchers in kernels.h.
 #pragma once
+#include <map>
 #include <string>
 #include <vector>
 
@@ -136,6 +137,8 @@ struct mmvqa_engine {
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
   int use_side = 1;
+  // ---- per-geometry tap-validity tables of the 3x3 weight gradients (mmvqa_gemm_desc.pixmask), built on first use
+  std::map<std::string, int*> pixmasks;
   // ---- gradient-ready notifications (data-parallel overlap): called on the host right after the kernels that
   // complete grads[lo, hi) have been enqueued and the main stream has been ordered behind them
   void (*grad_cb)(void* user, long long lo, long long hi) = nullptr;

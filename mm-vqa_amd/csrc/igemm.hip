@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     uint32_t a_ok, b_ok;       // bit r: chunk r holds real data
     f32x4 ac0, ac1, ac2;      // A-prologue coefficients of this tile's channels
     int tm[NAC];              // fast loaders: all-ones / zero halo mask of chunk r at this tile's tap
+    int pm[NBC], tmb[NBC];    // weight gradient of a 3x3: tap-validity words of the stage's NEXT tile / B mask of this tile
   };
 
   f32x16 acc[TM][TN];
@@ -505,8 +506,9 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     // instruction's soffset.  Rows / columns outside the matrix and halo taps use an offset beyond
     // num_records: the hardware range check returns zeros without touching memory.
     constexpr int BIG = (int)0x80000000;
-    __amdgpu_buffer_rsrc_t rA, rA2, rB, rC0, rC1, rC2;
-    int f_voffA[NAC], f_voffB[NBC];
+    __amdgpu_buffer_rsrc_t rA, rA2, rB, rC0, rC1, rC2, rT;
+    int f_voffA[NAC], f_voffB[NBC], f_voffT[NBC], f_veB[NBC];
+    int f_runT = 0, f_tapw = 0;                   // weight gradient of a 3x3: pixel-table offset, the workgroup's tap
     const int f_voffC = a_kq * 4;
     int f_tap = 0, f_c = 0, f_kh = 0, f_kw = 0;   // (tap, channel) of the next K-tile to load: wave-uniform
     int f_runA = 0, f_runB = 0;                   // running byte offsets of the plain (non-gather) operands
@@ -553,11 +555,27 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
 #pragma unroll
         for (int r = 0; r < NBC; ++r)
           f_voffB[r] = b_colvalid ? ((bkm_k0 + B_KSTEP * r) * p.b_ld + b_base[r]) * 4 : BIG;
-      } else {
+      } else if constexpr (FAST == 1) {
         rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.K * p.b_ld * 4, FLAGS);
 #pragma unroll
         for (int r = 0; r < NBC; ++r) f_voffB[r] = b_colvalid ? (b_base[r] * p.b_ld + b_ci) * 4 : BIG;
+      } else {
+        // 3x3 (stride 1, "same") weight gradient: every column of this workgroup belongs to ONE filter tap
+        // (Cs % BN == 0), so the gathered input row of output pixel m is row m shifted by a workgroup-uniform
+        // amount; which pixels have that tap inside the image comes from the per-pixel table p.pixmask.
+        f_tapw = n0 / p.g_Cs;
+        const int kh = f_tapw / p.g_KW, kw = f_tapw - kh * p.g_KW;
+        rB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B - (p.g_pad * p.g_SW + p.g_pad) * p.b_ld), 0, NREC, FLAGS);
+        rT = __builtin_amdgcn_make_buffer_rsrc((void*)p.pixmask, 0, p.K * 4, FLAGS);
+        f_runB = (kh * p.g_SW + kw) * p.b_ld * 4;
+#pragma unroll
+        for (int r = 0; r < NBC; ++r) {
+          f_voffB[r] = b_colvalid ? (b_base[r] * p.b_ld + b_ci) * 4 : BIG;
+          f_voffT[r] = b_base[r] * 4;
+        }
       }
+#pragma unroll
+      for (int r = 0; r < NBC; ++r) f_veB[r] = f_voffB[r];
     }
     // One K-tile of fast loads in four steps, so that the pipelined loop can place them:
     //   f_halo    (VALU, FAST == 2 only): per-chunk halo mask and effective offset for the tile at (f_tap, f_c);
@@ -567,8 +585,21 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     int f_ve[NAC];
 #pragma unroll
     for (int r = 0; r < NAC; ++r) f_ve[r] = (FAST != 0) ? f_voffA[r] : 0;
+    auto tload = [&](int voff, int soff) __attribute__((always_inline)) {
+      return __builtin_amdgcn_raw_buffer_load_b32(rT, voff, soff, 0);
+    };
     auto f_halo = [&](Stage& S) __attribute__((always_inline)) {
-      if constexpr (FAST == 2) {
+      if constexpr (FAST == 2 && KIND == KIND_WGRAD) {
+        // consume the table words of the tile at the current position, then fetch those of the tile this stage
+        // receives after it (two K-tiles on): a table word is always a whole iteration old when it is needed
+#pragma unroll
+        for (int r = 0; r < NBC; ++r) {
+          const int t = __builtin_amdgcn_sbfe(S.pm[r], f_tapw, 1);
+          S.tmb[r] = t;
+          f_veB[r] = (t & f_voffB[r]) | (~t & BIG);
+          S.pm[r] = tload(f_voffT[r], f_runT + 2 * BK * 4);
+        }
+      } else if constexpr (FAST == 2) {
 #pragma unroll
         for (int r = 0; r < NAC; ++r) {
           const int t = __builtin_amdgcn_sbfe((int)a_mask[r], f_tap & 31, 1);
@@ -599,7 +630,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
         S.ra[i] = bload(rA, f_ve[i], f_sA);
         if constexpr (A_TWO) S.ra2[i] = bload(rA2, f_ve[i], f_sA);
       } else {
-        S.rb[i - NAC] = bload(rB, f_voffB[i - NAC], f_sB);
+        S.rb[i - NAC] = bload(rB, f_veB[i - NAC], f_sB);
       }
     };
     auto f_advance = [&]() __attribute__((always_inline)) {
@@ -613,6 +644,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
       } else {
         f_runA += BK * p.a_ld * 4;
         f_runB += BK * p.b_ld * 4;
+        f_runT += BK * 4;
       }
     };
     auto fload_piece = [&](Stage& S, int i) __attribute__((always_inline)) {   // piece view used by LT
@@ -629,7 +661,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
         f32x4 v = S.ra[r];
         if constexpr (APRO == PRO_AFFINE_RELU) {
           const f32x2 lo = __builtin_elementwise_fma(v.xy, S.ac0.xy, S.ac1.xy), hi = __builtin_elementwise_fma(v.zw, S.ac0.zw, S.ac1.zw);
-          if constexpr (FAST == 2) {
+          if constexpr (FAST == 2 && A_ROWK) {
             const float lim = __builtin_bit_cast(float, S.tm[r] & 0x7f800000);   // +inf where the tap is inside the image, else 0
             v[0] = __builtin_amdgcn_fmed3f(lo[0], 0.f, lim); v[1] = __builtin_amdgcn_fmed3f(lo[1], 0.f, lim);
             v[2] = __builtin_amdgcn_fmed3f(hi[0], 0.f, lim); v[3] = __builtin_amdgcn_fmed3f(hi[1], 0.f, lim);
@@ -641,7 +673,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
           f32x2 lo = __builtin_elementwise_fma(z.xy, S.ac1.xy, S.ac2.xy), hi = __builtin_elementwise_fma(z.zw, S.ac1.zw, S.ac2.zw);
           lo = __builtin_elementwise_fma(v.xy, S.ac0.xy, lo); hi = __builtin_elementwise_fma(v.zw, S.ac0.zw, hi);
           v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
-          if constexpr (FAST == 2) {   // halo taps: zero (the loads returned 0, the affine part did not)
+          if constexpr (FAST == 2 && A_ROWK) {   // halo taps: zero (the loads returned 0, the affine part did not)
             typedef int i32x4 __attribute__((ext_vector_type(4)));
             const int tmask = S.tm[r];
             const i32x4 vi = __builtin_bit_cast(i32x4, v) & i32x4{tmask, tmask, tmask, tmask};
@@ -658,7 +690,13 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
         f32x4 v = S.rb[r];
         if constexpr (KIND == KIND_WGRAD && BPRO == PRO_AFFINE_RELU) {
           const f32x2 lo = __builtin_elementwise_fma(v.xy, bc0.xy, bc1.xy), hi = __builtin_elementwise_fma(v.zw, bc0.zw, bc1.zw);
-          v[0] = fmaxf(lo[0], 0.f); v[1] = fmaxf(lo[1], 0.f); v[2] = fmaxf(hi[0], 0.f); v[3] = fmaxf(hi[1], 0.f);
+          if constexpr (FAST == 2) {
+            const float lim = __builtin_bit_cast(float, S.tmb[r] & 0x7f800000);   // +inf where the tap is inside the image, else 0
+            v[0] = __builtin_amdgcn_fmed3f(lo[0], 0.f, lim); v[1] = __builtin_amdgcn_fmed3f(lo[1], 0.f, lim);
+            v[2] = __builtin_amdgcn_fmed3f(hi[0], 0.f, lim); v[3] = __builtin_amdgcn_fmed3f(hi[1], 0.f, lim);
+          } else {
+            v[0] = fmaxf(lo[0], 0.f); v[1] = fmaxf(lo[1], 0.f); v[2] = fmaxf(hi[0], 0.f); v[3] = fmaxf(hi[1], 0.f);
+          }
         }
         if constexpr (B_ROWK) {
           *reinterpret_cast<f32x4*>(&bs[(b_r0 + RSTEP * r) * LDK + b_kq]) = v;
@@ -708,6 +746,10 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     S0.a_ok = S0.b_ok = S1.a_ok = S1.b_ok = 0;
     S0.ac0 = S1.ac0 = ac0_i; S0.ac1 = S1.ac1 = ac1_i; S0.ac2 = S1.ac2 = ac2_i;
 
+    if constexpr (FAST == 2 && KIND == KIND_WGRAD) {
+#pragma unroll
+      for (int r = 0; r < NBC; ++r) { S0.pm[r] = tload(f_voffT[r], 0); S1.pm[r] = tload(f_voffT[r], BK * 4); }
+    }
     if (nkt > 0) {
       LT(S0, kt_begin);
       if constexpr (TM * TN == 1) LT(S1, kt_begin + 1);
@@ -888,6 +930,14 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
           if (p.b_pro == PRO_AFFINE_RELU) run(I2{}, I1{}, F1{}); else run(I2{}, I0{}, F1{});
         } else {
           if (p.b_pro == PRO_AFFINE_RELU) run(I0{}, I1{}, F1{}); else run(I0{}, I0{}, F1{});
+        }
+      } else if (x.fast == 2) {
+        if constexpr (TM * TN == 1) {
+          if (p.a_pro == PRO_DZ) {
+            if (p.b_pro == PRO_AFFINE_RELU) run(I2{}, I1{}, F2{}); else run(I2{}, I0{}, F2{});
+          } else {
+            if (p.b_pro == PRO_AFFINE_RELU) run(I0{}, I1{}, F2{}); else run(I0{}, I0{}, F2{});
+          }
         }
       } else if (p.a_pro == PRO_DZ) {
         switch (p.b_pro) {
@@ -1221,7 +1271,7 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
   x.ow = make_fastdiv(p.g_OW);
   // uniform-tap loaders: a K-tile never straddles a filter tap, nothing ragged, 31-bit byte offsets
   x.fast = 0;
-  if (!NCHW && p.K % BK == 0 && !p.gate && !getenv("MMVQA_IGEMM_GENERAL")) {
+  if (!NCHW && (p.K % BK == 0 || (KIND == KIND_WGRAD && p.pixmask)) && !p.gate && !getenv("MMVQA_IGEMM_GENERAL")) {
     const int taps = p.g_KH * p.g_KW;
     const double lim = 2147483648.0 - 16777216.0;
     if (KIND != KIND_WGRAD) {
@@ -1235,9 +1285,15 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
         x.fast = (taps > 1 || (KIND == KIND_DGRAD && p.g_stride > 1)) ? 2 : 1;
     } else {
       const bool pro_ok = (p.a_pro == PRO_NONE || p.a_pro == PRO_DZ) && (p.b_pro == PRO_NONE || p.b_pro == PRO_AFFINE_RELU);
-      if (pro_ok && taps == 1 && p.g_stride == 1 && p.g_pad == 0 && p.M % 4 == 0 && p.N % 4 == 0 &&
+      if (pro_ok && taps == 1 && p.K % BK == 0 && p.g_stride == 1 && p.g_pad == 0 && p.M % 4 == 0 && p.N % 4 == 0 &&
           (double)p.K * p.a_ld * 4.0 < lim && (double)p.K * p.b_ld * 4.0 < lim)
         x.fast = 1;
+      // 3x3-like "same" convolution, stride 1, with the caller's tap-validity table; pixels past K are masked by
+      // the table's range check, so K need not be a multiple of the K-tile here
+      else if (pro_ok && taps > 1 && taps <= 32 && p.pixmask && p.g_stride == 1 && p.g_OH == p.g_SH && p.g_OW == p.g_SW &&
+               2 * p.g_pad == p.g_KH - 1 && p.g_KH == p.g_KW && BM == 64 && BN == 64 && p.g_Cs % BN == 0 && p.M % 4 == 0 &&
+               (double)p.K * p.a_ld * 4.0 < lim && (double)(p.K + (double)p.g_SW * p.g_KH) * p.b_ld * 4.0 < lim)
+        x.fast = 2;
     }
   }
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splitk);

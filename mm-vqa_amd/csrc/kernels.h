@@ -55,6 +55,7 @@ int k_adam(hipStream_t st, float* p, float* g, float* m, float* v, long n, doubl
 int k_axpy(hipStream_t st, float* y, const float* x, float a, long n);
 int k_colsum(hipStream_t st, const float* x, int ld, int rows, int cols, float* out);
 int k_dropout(hipStream_t st, float* x, long n, float p, uint32_t seed);
+int k_pixmask(hipStream_t st, int* out, int N, int OH, int OW, int SH, int SW, int KH, int KW, int stride, int pad);
 int k_dropout_copy(hipStream_t st, const float* x, float* y, long n, float p, uint32_t seed);
 
 // EfficientNetV2 pieces (elementwise.hip)

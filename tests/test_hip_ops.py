@@ -169,6 +169,22 @@ def test_conv_fwd_bwd(cfg):
     d.b_pro, d.b_c0, d.b_c1 = L.PRO_AFFINE_RELU, P(scd), P(shd)
     run_igemm(d, L.KIND_WGRAD)
     assert_close(dw.view(Cout, K, K, Cin).permute(0, 3, 1, 2), wr.grad, TOL, "wgrad")
+    if K > 1 and s == 1 and OH == H and Cin % 64 == 0:
+        # the same weight gradient through the uniform-tap loaders: per-pixel tap-validity table + 64x64 tiles
+        tab = torch.zeros(N * OH * OW, dtype=torch.int32, device=dev())
+        L.check(L.lib().mmvqa_pixmask(L.stream_ptr(), P(tab), N, OH, OW, H, W, K, K, s, p))
+        ref_tab = torch.zeros(N, OH, OW, dtype=torch.int32)
+        for kh in range(K):
+            for kw in range(K):
+                ys, xs = torch.arange(OH) * s - p + kh, torch.arange(OW) * s - p + kw
+                ok = ((ys >= 0) & (ys < H))[:, None] & ((xs >= 0) & (xs < W))[None, :]
+                ref_tab += (ok.int() << (kh * K + kw))[None]
+        assert torch.equal(tab.cpu().view(N, OH, OW), ref_tab)
+        d.pixmask = P(tab)
+        for tile in (3, 5):
+            dw.zero_()
+            run_igemm(d, L.KIND_WGRAD, tile=tile)
+            assert_close(dw.view(Cout, K, K, Cin).permute(0, 3, 1, 2), wr.grad, TOL, f"wgrad (pixel table, tile {tile})")
 
 
 def test_stem_conv():
