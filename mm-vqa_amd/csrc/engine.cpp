@@ -504,6 +504,18 @@ static int lin_dgrad(mmvqa_engine* e, hipStream_t st, const float* dy, int dy_ld
   g.B = PRM(L.w); g.b_ld = L.in; g.b_tapstride = 0;
   g.C = dx; g.c_ld = dx_ld;
   g.dact = dact; g.Pre = Pre; g.pre_ld = pre_ld; g.colsum = colsum; g.R = R; g.r_ld = r_ld;
+  // Few output tiles and a long contraction (the vocabulary-sized decoder: 96 tiles x 477 K-tiles): split K over
+  // workgroups and accumulate with atomics into the zeroed output.  Only for a plain epilogue.
+  const long tiles = ((M + 63) / 64) * ((L.in + 63) / 64);
+  if (!dact && !colsum && !R && tiles < 256 && L.out >= 1536 && dx_ld == L.in) {
+    int sk = (int)((512 + tiles - 1) / tiles);
+    const int maxs = (L.out / 64) / 8;
+    if (sk > maxs) sk = maxs;
+    if (sk > 1) {
+      HIP_CHECK_RET(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * dx_ld, st));
+      g.c_atomic = 1; g.splitk = sk;
+    }
+  }
   RUN(PROF_IGEMM, 2.0 * M * L.out * L.in, mmvqa_launch_igemm(g, KIND_DGRAD, 0, 0, st));
   return MMVQA_OK;
 }
@@ -737,7 +749,11 @@ static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
     RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 1, 0, st));
     TRY(bn_coef_fwd(e, st, e->stem_bn));
   }
-  TRY(tap_fwd(e, st, 4, WS(e->z0), &e->stem_bn));
+  // The five taps (1x1 conv -> act -> global average pool) and the downsample convolutions do not feed the
+  // bottleneck chain: they run on the side stream beside it (most of the chain's launches fill 196 of 256 CUs).
+  SideCtx sc(e, st);
+  sc.fork();
+  TRY(tap_fwd(e, sc.sd, 4, WS(e->z0), &e->stem_bn));
   RUN(PROF_OTHER, 0, k_maxpool_fwd(st, WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), WS(e->p0),
                                    reinterpret_cast<unsigned char*>(WS(e->pool_idx)), B, e->SH, e->SW, w, e->PH,
                                    e->PW));
@@ -745,12 +761,18 @@ static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
   int layer = 0;
   for (size_t i = 0; i < e->blocks.size(); ++i) {
     BlockRef& b = e->blocks[i];
+    hipEvent_t ev_ds = nullptr;
+    if (b.has_ds) {
+      sc.fork();
+      TRY(conv_fwd(e, sc.sd, b.cd, x, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.zd), b.bd));
+      ev_ds = sc.mark();
+    }
     TRY(conv_fwd(e, st, b.c1, x, nullptr, B, b.H, b.W, b.H, b.W, WS(b.z1), b.b1));
     TRY(conv_fwd(e, st, b.c2, WS(b.z1), &b.b1, B, b.H, b.W, b.OH, b.OW, WS(b.z2), b.b2));
     TRY(conv_fwd(e, st, b.c3, WS(b.z2), &b.b2, B, b.OH, b.OW, b.OH, b.OW, WS(b.z3), b.b3));
     const long rows = (long)B * b.OH * b.OW;
     if (b.has_ds) {
-      TRY(conv_fwd(e, st, b.cd, x, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.zd), b.bd));
+      sc.need(ev_ds);
       RUN(PROF_OTHER, 0, k_bn_add_relu(st, WS(b.z3), WS(b.b3.scale), WS(b.b3.shift), WS(b.zd), WS(b.bd.scale),
                                        WS(b.bd.shift), WS(b.out), rows, b.c3.Cout));
     } else {
@@ -759,10 +781,12 @@ static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
     }
     x = WS(b.out);
     if ((int)i == e->layer_end[layer]) {
-      TRY(tap_fwd(e, st, 3 - layer, x, nullptr));
+      sc.fork();
+      TRY(tap_fwd(e, sc.sd, 3 - layer, x, nullptr));
       ++layer;
     }
   }
+  sc.need(sc.mark());   // join: the embedding reads the visual tokens
   return MMVQA_OK;
 }
 
@@ -1348,6 +1372,7 @@ int engine_forward(mmvqa_engine* e, hipStream_t st, const float* img, const long
   e->logits = logits; e->logits_ld = logits_ld; e->feat = feat;
   e->training = training; e->seed = seed;
   struct TunerScope { TunerScope(IgemmTuner* t) { mmvqa_set_tuner(t); } ~TunerScope() { mmvqa_set_tuner(nullptr); } } ts(&e->tuner);
+  e->ev_next = 0;
   if (d.cnn == 1) TRY(effnet_forward(e, st)); else TRY(resnet_forward(e, st));
   const float pe = training ? d.p_emb_drop : 0.f;
   RUN(PROF_OTHER, 0,

@@ -81,6 +81,10 @@ def main():
                     d = conv_desc_wgrad(g, x, N, H, W, Cin, Cout, K, s, p, dw)
                     d.A2, d.a_pro, d.a_c0, d.a_c1, d.a_c2 = P(z), L.PRO_DZ, P(c3[0]), P(c3[1]), P(c3[2])
                     d.b_pro, d.b_c0, d.b_c1 = L.PRO_AFFINE_RELU, P(sc), P(sh)
+                    if K > 1 and s == 1 and OH == H:
+                        tab = torch.zeros(N * OH * OW, dtype=torch.int32, device=dev())
+                        L.check(L.lib().mmvqa_pixmask(L.stream_ptr(), P(tab), N, OH, OW, H, W, K, K, s, p))
+                        d.pixmask = P(tab)
                     kd = L.KIND_WGRAD
                 us = timeit(lambda: L.check(L.lib().mmvqa_igemm(C.byref(d), kd, 0, tile, L.stream_ptr())))
                 print(f"{name:14s} {kind:6s} {tile:4d} {d.M:7d} {d.N:6d} {d.K:6d} {us:9.1f} {flops / us / 1e6:8.1f}", flush=True)
