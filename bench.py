@@ -163,6 +163,10 @@ def main():
     log(f"timed {a.steps} steps: {ms:.2f} ms/step")
     value = B_PER_GPU * world * a.steps / dt
 
+    # Roofline of the dominant kernel class: one more step, identical to the timed ones (same two HIP streams), with
+    # a HIP event pair around every launch recorded on the stream that launch goes to.  The weight-gradient GEMMs
+    # run beside the data-gradient chain, so a launch's duration includes the time it shares the chip: the average
+    # agrees with the steady-state rocprofv3 kernel trace (profiles/round1_c_kernel_stats_steady_cfg2.csv).
     roof = None
     if not a.no_roofline:
         model.profile(True)
@@ -172,6 +176,12 @@ def main():
         model.profile(False)
         g = pr["igemm"]
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        model.profile(True, serialized=True)   # the same step on ONE stream: every launch has the chip to itself
+        step()
+        torch.cuda.synchronize()
+        gs = model.profile_read()["igemm"]
+        model.profile(False)
+        ach_alone = gs["flops"] / (gs["ms"] * 1e-3) / 1e12 if gs["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "round1_igemm_traffic.json")
         if CONFIG == 2 and os.path.exists(tf):   # HBM bytes per launch from the committed rocprofv3 PMC passes
@@ -181,6 +191,9 @@ def main():
                     frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src, kernel="igemm_kernel (fp32 MFMA implicit GEMM)",
                     launches_per_step=g["launches"], avg_launch_us=g["ms"] * 1e3 / max(1, g["launches"]),
                     algorithmic_gflop_per_step=g["flops"] / 1e9,
+                    single_stream=dict(achieved=ach_alone, frac=ach_alone / PEAK_F32_MFMA_TFLOPS,
+                                       avg_launch_us=gs["ms"] * 1e3 / max(1, gs["launches"]),
+                                       note="same step with the second HIP stream disabled: no launch shares the chip"),
                     other_ms_per_step=dict(attention=pr["attention"]["ms"], elementwise=pr["other"]["ms"]))
 
     wl = ("pretrain/roco_train.py MLM-only: resnet152 + transformer(4 layers, 12 heads), " if CONFIG == 2 else

@@ -256,7 +256,9 @@ int mmvqa_engine_set_grad_callback(mmvqa_engine* e, mmvqa_grad_cb cb, void* user
  * Returns the number of tuned shapes so far (>= 0) or a negative error. */
 int mmvqa_engine_tune(mmvqa_engine* e, int enable);
 /* per-kernel-class timing (HIP events on the launch stream) of the NEXT forward+backward:
- * enable, run, then read back {n_launches, total_ms, algorithmic_flops} per class */
+ * enable, run, then read back {n_launches, total_ms, algorithmic_flops} per class.
+ * enable = 1: as the step normally runs (weight-gradient GEMMs on the second stream beside the data-gradient chain, so
+ * a launch's time includes sharing the chip); enable = 2: everything on one stream; 0: off (both streams again) */
 int mmvqa_engine_profile(mmvqa_engine* e, int enable);
 int mmvqa_engine_profile_read(mmvqa_engine* e, int cls, long long* launches, double* ms, double* flops);
 

@@ -224,7 +224,8 @@ int mmvqa_engine_tune(mmvqa_engine* e, int enable) {
 }
 int mmvqa_engine_profile(mmvqa_engine* e, int enable) {
   if (!e) return mmvqa_set_error(MMVQA_ERR_ARG, "profile: null engine");
-  e->prof_on = enable;
+  e->prof_on = enable ? 1 : 0;
+  e->use_side = enable == 2 ? 0 : 1;   // 2: one stream only, every launch has the chip to itself
   if (enable) {
     memset(e->prof_launch, 0, sizeof(e->prof_launch));
     memset(e->prof_ms, 0, sizeof(e->prof_ms));

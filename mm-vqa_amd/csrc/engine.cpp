@@ -693,7 +693,7 @@ struct SideCtx {
   hipStream_t st, sd;
   bool on;
   SideCtx(mmvqa_engine* e_, hipStream_t st_) : e(e_), st(st_) {
-    on = e->use_side && !e->prof_on && !e->tuner.tuning;
+    on = e->use_side && !e->tuner.tuning;   // (the per-launch profiler records its events on the launching stream)
     if (on && !e->side) on = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess;
     sd = on ? e->side : st;
   }

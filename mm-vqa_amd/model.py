@@ -407,8 +407,9 @@ class Model(nn.Module):
         return n
 
     # ------------------------------------------------------------------ profiling (bench.py)
-    def profile(self, enable: bool):
-        L.check(L.lib().mmvqa_engine_profile(self._handle, 1 if enable else 0))
+    def profile(self, enable, serialized: bool = False):
+        """per-launch HIP-event timing of the next step; serialized=True puts every launch on one stream"""
+        L.check(L.lib().mmvqa_engine_profile(self._handle, (2 if serialized else 1) if enable else 0))
 
     def profile_read(self):
         out = {}
