@@ -111,6 +111,8 @@ def test_dgrad_fused_act_backward():
 CONVS = [  # N, H, W, Cin, Cout, K, stride, pad
     (2, 9, 9, 8, 16, 3, 1, 1), (2, 9, 9, 8, 16, 3, 2, 1), (3, 8, 8, 16, 24, 1, 1, 0), (2, 9, 9, 16, 8, 1, 2, 0),
     (2, 14, 14, 64, 64, 3, 1, 1), (1, 7, 7, 40, 72, 3, 2, 1),
+    # channel counts that are multiples of the K-tile: the uniform-tap loaders (1x1, strided 3x3, strided 1x1)
+    (2, 10, 10, 128, 64, 1, 1, 0), (2, 12, 12, 64, 128, 3, 2, 1), (2, 12, 12, 64, 128, 1, 2, 0), (3, 8, 8, 128, 128, 3, 1, 1),
 ]
 
 
