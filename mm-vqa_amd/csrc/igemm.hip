@@ -634,6 +634,9 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
       }
     };
     auto f_advance = [&]() __attribute__((always_inline)) {
+#ifdef EXP_NOADVANCE   // experiment: every K-tile re-reads the first tile (valid addresses, cache-resident)
+      return;
+#endif
       if constexpr (A_ROWK) {
         f_c += BK;
         if (f_c >= p.g_Cs) {

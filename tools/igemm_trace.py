@@ -2,7 +2,11 @@
 """Per-workgroup phase timeline of the implicit-GEMM kernel (s_memtime stamps written by a -DIGEMM_TRACE build
 of the library, built on the fly into tools/build/).  For every shape: span of the launch, the ramp of workgroup
 start times, and the mean time a workgroup spends in setup / first tile / K loop / epilogue.
-    python tools/igemm_trace.py --filter l3 --kinds fwd --tiles 3,5"""
+    python tools/igemm_trace.py --filter l3 --kinds fwd --tiles 3,5
+
+Ablations: IGEMM_EXP="-DEXP_X" builds a variant library (results are wrong, timings are the point):
+EXP_NOLOAD / EXP_NOSTORE / EXP_NOBAR (drop the K loop's global loads / LDS-write block / barrier), EXP_SAMETILE (every
+workgroup loads workgroup (0,0)'s tiles), EXP_NOADVANCE (every K-tile re-reads the first), EXP_NOSTOREC (no output store)."""
 import argparse
 import ctypes as C
 import os
