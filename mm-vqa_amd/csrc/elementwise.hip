@@ -14,7 +14,7 @@ static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
 __global__ void bn_coef_fwd_kernel(const double* __restrict__ stat, int C, double count, float eps,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ run_mean, float* __restrict__ run_var,
-                                   long long* __restrict__ nbt, float momentum, int reps, int training,
+                                   long long* __restrict__ nbt, double keep, int reps, int training,
                                    float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -33,7 +33,6 @@ __global__ void bn_coef_fwd_kernel(const double* __restrict__ stat, int C, doubl
     mean = (float)mu;
     invstd = (float)(1.0 / sqrt(var + (double)eps));
     if (run_mean) {
-      double keep = pow(1.0 - (double)momentum, (double)reps);
       double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
       run_mean[c] = (float)(keep * (double)run_mean[c] + (1.0 - keep) * mu);
       run_var[c] = (float)(keep * (double)run_var[c] + (1.0 - keep) * unb);
@@ -783,7 +782,8 @@ int k_bn_coef_fwd(hipStream_t st, const double* stat, int C, double count, float
                   const float* beta, float* run_mean, float* run_var, long long* nbt, float momentum, int reps,
                   int training, float* scale, float* shift, float* mean, float* invstd) {
   hipLaunchKernelGGL(bn_coef_fwd_kernel, dim3(cdiv_i(C, 256)), dim3(256), 0, st, stat, C, count, eps, gamma, beta,
-                     run_mean, run_var, nbt, momentum, reps, training, scale, shift, mean, invstd);
+                     run_mean, run_var, nbt, pow(1.0 - (double)momentum, (double)reps), reps, training, scale, shift,
+                     mean, invstd);   // (1 - momentum)^reps on the host: a double pow() per thread was most of the kernel's math
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }

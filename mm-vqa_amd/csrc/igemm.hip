@@ -1337,7 +1337,7 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     if (!g_tuner->tuning) return launch_one(p, kind, nchw, 0, stream);
     struct Cand { int tile, splitk; };
     std::vector<Cand> cands;
-    const int tiles_f[] = {1, 2, 3, 5}, tiles_w[] = {1, 2, 3};
+    const int tiles_f[] = {1, 2, 3, 4, 5}, tiles_w[] = {1, 2, 3, 4};
     if (kind == KIND_WGRAD && p.splitk <= 0) {
       for (int t : tiles_w) for (int sk : {0, 1, 2, 4, 8, 16}) cands.push_back({t, sk});
     } else if (kind == KIND_WGRAD) {
