@@ -1337,7 +1337,7 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     if (!g_tuner->tuning) return launch_one(p, kind, nchw, 0, stream);
     struct Cand { int tile, splitk; };
     std::vector<Cand> cands;
-    const int tiles_f[] = {1, 2, 3, 4, 5}, tiles_w[] = {1, 2, 3, 4};
+    const int tiles_f[] = {1, 2, 3, 4, 5, 6}, tiles_w[] = {1, 2, 3, 4, 6};
     if (kind == KIND_WGRAD && p.splitk <= 0) {
       for (int t : tiles_w) for (int sk : {0, 1, 2, 4, 8, 16}) cands.push_back({t, sk});
     } else if (kind == KIND_WGRAD) {
@@ -1371,7 +1371,8 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
   return launch_one(p, kind, nchw, it->second.first, stream);
 }
 
-// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 (BK 64), 4 = 64x128, 5 = 64x64 with 8 waves (K-tile split in 2)
+// tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 (BK 64), 4 = 64x128, 5 = 64x64 with 8 waves (K-tile split in 2),
+//       6 = 64x64 with BK 32 (37 KB of LDS: four workgroups per CU for short contractions with many tiles)
 static int launch_one(GemmParams p, int kind, int nchw, int tile, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MMVQA_OK;
   if (p.g_KH <= 0) { p.g_KH = p.g_KW = 1; p.g_stride = 1; p.g_pad = 0; }
@@ -1427,6 +1428,7 @@ static int launch_one(GemmParams p, int kind, int nchw, int tile, hipStream_t st
     case 1: GO(128, 128, 32);
     case 2: GO(128, 64, 32);
     case 4: GO(64, 128, 32);
+    case 6: GO(64, 64, 32);
     case 5:
       if (kind == KIND_FWD) return launch_cfg<64, 64, 64, KIND_FWD, false, 2>(p, stream);
       return launch_cfg<64, 64, 64, KIND_DGRAD, false, 2>(p, stream);
