@@ -1337,7 +1337,7 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     if (!g_tuner->tuning) return launch_one(p, kind, nchw, 0, stream);
     struct Cand { int tile, splitk; };
     std::vector<Cand> cands;
-    const int tiles_f[] = {1, 2, 3, 4, 5, 6}, tiles_w[] = {1, 2, 3, 4, 6};
+    const int tiles_f[] = {1, 2, 3, 4, 5, 6}, tiles_w[] = {1, 2, 3, 4, 5, 6};
     if (kind == KIND_WGRAD && p.splitk <= 0) {
       for (int t : tiles_w) for (int sk : {0, 1, 2, 4, 8, 16}) cands.push_back({t, sk});
     } else if (kind == KIND_WGRAD) {
@@ -1391,7 +1391,6 @@ static int launch_one(GemmParams p, int kind, int nchw, int tile, hipStream_t st
     // few workgroups and a long contraction: 8 waves per workgroup (two per SIMD)
     if (tile == 3 && kind != KIND_WGRAD && (long)cdiv(p.M, 64) * cdiv(p.N, 64) < 400 && p.K >= 512) tile = 5;
   }
-  if (tile == 5 && kind == KIND_WGRAD) tile = 3;
   if (nchw) tile = (kind == KIND_FWD) ? 2 : 3;
   const int bm = (tile == 1 || tile == 2) ? 128 : 64;
   const int bn = (tile == 1 || tile == 4) ? 128 : 64;
@@ -1431,7 +1430,8 @@ static int launch_one(GemmParams p, int kind, int nchw, int tile, hipStream_t st
     case 6: GO(64, 64, 32);
     case 5:
       if (kind == KIND_FWD) return launch_cfg<64, 64, 64, KIND_FWD, false, 2>(p, stream);
-      return launch_cfg<64, 64, 64, KIND_DGRAD, false, 2>(p, stream);
+      if (kind == KIND_DGRAD) return launch_cfg<64, 64, 64, KIND_DGRAD, false, 2>(p, stream);
+      return launch_cfg<64, 64, 64, KIND_WGRAD, false, 2>(p, stream);
     default: GO(64, 64, 64);
   }
 #undef GO
