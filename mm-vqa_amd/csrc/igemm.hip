@@ -105,6 +105,7 @@ template <int BM, int BN, int BK, int KIND, bool NCHW, int KS>
 __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, const GemmAux x) {
   constexpr int NT = 256 * KS;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr bool PIPE = TM * TN <= 2;         // slot-pipelined K loop (one or two 32x32 tiles per wave); else the plain loop
   constexpr int LDK = BK + 4;
   constexpr int KQ = BK / 4;                 // float4 per row of a [row][k] tile
   constexpr int RSTEP = NT / KQ;             // rows covered by one pass of the NT threads
@@ -755,10 +756,10 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     }
     if (nkt > 0) {
       LT(S0, kt_begin);
-      if constexpr (TM * TN == 1) LT(S1, kt_begin + 1);
+      if constexpr (PIPE) LT(S1, kt_begin + 1);
 #pragma unroll
       for (int c = 0; c < NC; ++c) SC(S0, 0, kt_begin, c);
-      if constexpr (FAST != 0 && TM * TN == 1) f_halo(S0);   // S0 receives tile kt_begin + 2 next
+      if constexpr (FAST != 0 && PIPE) f_halo(S0);   // S0 receives tile kt_begin + 2 next
     }
     // No load may be pending across the loop entry: the wait-count pass merges the entry and the back-edge
     // states, and a load still in flight here turns into a vmcnt(0) at the loop head of EVERY iteration.
@@ -766,8 +767,8 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     __syncthreads();
     TRACE_MARK(2);
 
-    if constexpr (TM * TN == 1) {
-      // Software pipeline of the small tile, one fenced slot per MFMA.  A wave's MFMAs form a dependent
+    if constexpr (PIPE) {
+      // Software pipeline of the small tiles, one fenced slot per MFMA.  A wave's MFMAs form a dependent
       // chain (one 32x32 accumulator), so the next one issues 64 cycles after its predecessor and ~15 VALU
       // instructions fit in that shadow for free; anything clustered beyond that idles the matrix pipe.
       // Left to itself the machine scheduler clusters: it sank the global loads to the end of the iteration
@@ -782,8 +783,9 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
       //                            then the fragment read of tile t+1's group 0, hidden by 4 MFMAs.
       f32x4 fa[2][TM], fb[2][TN];
       read_frags(As, Bs, ks, fa[0], fb[0]);
-      constexpr int NS = NKG * 4;                 // MFMA slots of one K-tile (one 32x32 tile per wave)
-      constexpr int SB = NS - 4;                  // the barrier sits in front of the last k-group
+      constexpr int MPG = 4 * TM * TN;            // MFMAs of one k-group (8 deep) per wave
+      constexpr int NS = NKG * MPG;               // MFMA slots of one K-tile
+      constexpr int SB = NS - MPG;                // the barrier sits in front of the last k-group
       // A buffer_load_dwordx4 costs its wave ~25 cycles of texture-address time; the four waves of the
       // workgroup run in lockstep, so loads issued in consecutive slots queue behind each other (measured:
       // ~95 cycles per load per wave, 45 % of the MFMA time).  One load piece every LSTR-th slot keeps the
@@ -801,8 +803,9 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
         const float* as = As + buf * A_TILE;
         const float* bs = Bs + buf * B_TILE;
         static_for<NS>([&](auto SI) __attribute__((always_inline)) {
-          constexpr int sl = decltype(SI)::value, kk = sl / 4, j = sl % 4;
-          if constexpr (j == 0) {
+          constexpr int sl = decltype(SI)::value, kk = sl / MPG, g = sl % MPG;
+          constexpr int j = g / (TM * TN), ta = (g % (TM * TN)) / TN, tb = g % TN;
+          if constexpr (g == 0) {
             if constexpr (kk + 1 < NKG) {
               read_frags(as, bs, (kk + 1) * KS + ks, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
             } else {
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
               read_frags(As + (buf ^ 1) * A_TILE, Bs + (buf ^ 1) * B_TILE, ks, fa[0], fb[0]);
             }
           }
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][0][j], fb[kk & 1][0][j], acc[0][0], 0, 0, 0);
+          acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][ta][j], fb[kk & 1][tb][j], acc[ta][tb], 0, 0, 0);
 #ifndef EXP_NOLOAD
           if constexpr (FAST != 0) {
             // scalars in slot 1, then one buffer_load every FLS-th slot, all issued before the VALU slot SV
