@@ -1342,7 +1342,7 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     std::vector<Cand> cands;
     const int tiles_f[] = {1, 2, 3, 4, 5, 6}, tiles_w[] = {1, 2, 3, 4, 5, 6};
     if (kind == KIND_WGRAD && p.splitk <= 0) {
-      for (int t : tiles_w) for (int sk : {0, 1, 2, 4, 8, 16}) cands.push_back({t, sk});
+      for (int t : tiles_w) for (int sk : {0, 1, 2, 3, 4, 6, 8, 12, 16}) cands.push_back({t, sk});
     } else if (kind == KIND_WGRAD) {
       for (int t : tiles_w) cands.push_back({t, p.splitk});
     } else {
