@@ -104,6 +104,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: one process per GPU -- launch with "
+                 f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 "
+                 f"bench.py --gpus {a.gpus} ...`")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

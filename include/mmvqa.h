@@ -193,10 +193,17 @@ int mmvqa_meanpool_fwd(mmvqa_stream_t s, const float* h, const long long* mask, 
 int mmvqa_meanpool_bwd(mmvqa_stream_t s, const float* dout, const long long* mask, float* dh, int B, int T, int H,
                        int accumulate);
 /* log_softmax + NLLLoss() + masked argmax accuracy (pretrain/roco_utils.py:235-236,257-265).
- * out3 = {mean loss, #target>0, #correct}.  dlogits (nullable) = (softmax - onehot) * (*gscale_ptr) * gscale_mul */
+ * out3 = {mean loss, #target>0, #correct}; row_lse (nullable) = log sum exp of each row, kept for mmvqa_mlm_grad;
+ * dlogits (nullable) = (softmax - onehot) * (*gscale_ptr) * gscale_mul.  Rows that are 16-byte aligned with
+ * ld >= round_up(V,4) take the single-pass float4 kernels (one read of the logits); others a scalar form. */
 int mmvqa_mlm_loss(mmvqa_stream_t s, const float* logits, int ld, const long long* target, float* row_loss,
-                   long long* pred, float* dlogits, int dld, const float* gscale_ptr, float gscale_mul, int rows,
-                   int V, float* out3);
+                   float* row_lse, long long* pred, float* dlogits, int dld, const float* gscale_ptr, float gscale_mul,
+                   int rows, int V, float* out3);
+/* backward of the above from the saved row_lse: dlogits = (exp(logits - lse) - onehot) * (*gscale_ptr) * gscale_mul
+ * (gscale_ptr: device scalar = the upstream gradient of the mean loss, nullable); pad columns are zeroed.
+ * Requires aligned rows (see above). */
+int mmvqa_mlm_grad(mmvqa_stream_t s, const float* logits, int ld, const long long* target, const float* row_lse,
+                   float* dlogits, int dld, const float* gscale_ptr, float gscale_mul, int rows, int V);
 /* ASLSingleLabel (models/asl_singlelabel.py:23-53): per-sample losses + dlogits*gscale */
 int mmvqa_asl_loss(mmvqa_stream_t s, const float* logits, int ld, const long long* target, float* row_loss,
                    float* dlogits, int dld, int rows, int C, float gamma_pos, float gamma_neg, float eps,
@@ -205,8 +212,10 @@ int mmvqa_l2norm_fwd(mmvqa_stream_t s, const float* x, float* y, float* nrm, int
 int mmvqa_l2norm_bwd(mmvqa_stream_t s, const float* dy, const float* y, const float* nrm, float* dx, int rows,
                      int D);
 /* SupConLoss.forward(features) without labels/mask = SimCLR (models/SupConLoss/loss.py:21-98);
- * f is [2N][D] view-major */
-int mmvqa_supcon_loss(mmvqa_stream_t s, const float* f, float* loss, float* df, int N, int D, float temp,
+ * f is [2N][D] view-major (loss.py:57), D <= 256; df (nullable) = dloss/df * gscale; ws = 4*N floats of scratch
+ * (row log-sums and row losses).  Tiled over row blocks: any N (the all-gathered view set 2N*world of a
+ * data-parallel job, SURVEY 8(e) collective 2). */
+int mmvqa_supcon_loss(mmvqa_stream_t s, const float* f, float* loss, float* df, float* ws, int N, int D, float temp,
                       float base_temp, float gscale);
 /* torch.optim.Adam defaults over a flat buffer; g is scaled by gscale first and zeroed when zero_grad != 0 */
 int mmvqa_adam(mmvqa_stream_t s, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2,

@@ -89,11 +89,12 @@ SIGNATURES = {
     "mmvqa_embed_bwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _f, _u32, _i]),
     "mmvqa_meanpool_fwd": (_i, [_P, _P, _P, _P, _i, _i, _i]),
     "mmvqa_meanpool_bwd": (_i, [_P, _P, _P, _P, _i, _i, _i, _i]),
-    "mmvqa_mlm_loss": (_i, [_P, _P, _i, _P, _P, _P, _P, _i, _P, _f, _i, _i, _P]),
+    "mmvqa_mlm_loss": (_i, [_P, _P, _i, _P, _P, _P, _P, _P, _i, _P, _f, _i, _i, _P]),
+    "mmvqa_mlm_grad": (_i, [_P, _P, _i, _P, _P, _P, _i, _P, _f, _i, _i]),
     "mmvqa_asl_loss": (_i, [_P, _P, _i, _P, _P, _P, _i, _i, _i, _f, _f, _f, _f]),
     "mmvqa_l2norm_fwd": (_i, [_P, _P, _P, _P, _i, _i]),
     "mmvqa_l2norm_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i]),
-    "mmvqa_supcon_loss": (_i, [_P, _P, _P, _P, _i, _i, _f, _f, _f]),
+    "mmvqa_supcon_loss": (_i, [_P, _P, _P, _P, _P, _i, _i, _f, _f, _f]),
     "mmvqa_adam": (_i, [_P, _P, _P, _P, _P, _l, _d, _d, _d, _d, _i, _f, _i]),
     "mmvqa_axpy": (_i, [_P, _P, _P, _f, _l]),
     "mmvqa_colsum": (_i, [_P, _P, _i, _i, _i, _P]),

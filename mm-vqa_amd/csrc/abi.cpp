@@ -115,9 +115,13 @@ int mmvqa_meanpool_bwd(mmvqa_stream_t s, const float* dout, const long long* mas
   return k_meanpool_bwd(ST(s), dout, mask, dh, B, T, H, accumulate);
 }
 int mmvqa_mlm_loss(mmvqa_stream_t s, const float* logits, int ld, const long long* target, float* row_loss,
-                   long long* pred, float* dlogits, int dld, const float* gscale_ptr, float gscale_mul, int rows,
-                   int V, float* out3) {
-  return k_lsm_nll(ST(s), logits, ld, target, row_loss, pred, dlogits, dld, gscale_ptr, gscale_mul, rows, V, out3);
+                   float* row_lse, long long* pred, float* dlogits, int dld, const float* gscale_ptr, float gscale_mul,
+                   int rows, int V, float* out3) {
+  return k_lsm_nll(ST(s), logits, ld, target, row_loss, row_lse, pred, dlogits, dld, gscale_ptr, gscale_mul, rows, V, out3);
+}
+int mmvqa_mlm_grad(mmvqa_stream_t s, const float* logits, int ld, const long long* target, const float* row_lse,
+                   float* dlogits, int dld, const float* gscale_ptr, float gscale_mul, int rows, int V) {
+  return k_lsm_grad(ST(s), logits, ld, target, row_lse, dlogits, dld, gscale_ptr, gscale_mul, rows, V);
 }
 int mmvqa_asl_loss(mmvqa_stream_t s, const float* logits, int ld, const long long* target, float* row_loss,
                    float* dlogits, int dld, int rows, int C, float gamma_pos, float gamma_neg, float eps,
@@ -131,9 +135,9 @@ int mmvqa_l2norm_bwd(mmvqa_stream_t s, const float* dy, const float* y, const fl
                      int D) {
   return k_l2norm_bwd(ST(s), dy, y, nrm, dx, rows, D);
 }
-int mmvqa_supcon_loss(mmvqa_stream_t s, const float* f, float* loss, float* df, int N, int D, float temp,
+int mmvqa_supcon_loss(mmvqa_stream_t s, const float* f, float* loss, float* df, float* ws, int N, int D, float temp,
                       float base_temp, float gscale) {
-  return k_supcon(ST(s), f, loss, df, N, D, temp, base_temp, gscale);
+  return k_supcon(ST(s), f, loss, df, ws, N, D, temp, base_temp, gscale);
 }
 int mmvqa_adam(mmvqa_stream_t s, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2,
                double eps, int step, float gscale, int zero_grad) {

@@ -495,7 +495,8 @@ __global__ void meanpool_bwd_kernel(const float* __restrict__ dout, const long l
 // pretrain/roco_utils.py:235-236,257-265.  One workgroup per row.  Writes row loss
 // (lse - logit[target]), first-index argmax, and (optionally) dlogits = (softmax - onehot) * gscale.
 __global__ void lsm_nll_kernel(const float* __restrict__ logits, int ld, const long long* __restrict__ target,
-                               float* __restrict__ row_loss, long long* __restrict__ pred,
+                               float* __restrict__ row_loss, float* __restrict__ row_lse,
+                               long long* __restrict__ pred,
                                float* __restrict__ dlogits, int dld, const float* __restrict__ gscale_ptr,
                                float gscale_mul, int V) {
   __shared__ float red_m[4], red_s[4];
@@ -528,6 +529,7 @@ __global__ void lsm_nll_kernel(const float* __restrict__ logits, int ld, const l
   const long long tg = target[row];
   if (threadIdx.x == 0) {
     row_loss[row] = lse - x[tg];
+    if (row_lse) row_lse[row] = lse;
     pred[row] = mi;
   }
   if (dlogits) {
@@ -537,6 +539,107 @@ __global__ void lsm_nll_kernel(const float* __restrict__ logits, int ld, const l
       float pr = expf(x[i] - lse);
       d[i] = (pr - (i == tg ? 1.f : 0.f)) * gs;
     }
+  }
+}
+
+// ---- HBM-speed form of the same reduction (rows 16-byte aligned, ld >= round_up(V, 4)).
+// One 1024-thread workgroup per row (2 rows per CU in flight = full wave occupancy), ONE pass over the row with
+// float4 loads, LSM_U of them in flight per thread; a thread keeps a running (max, first index, sum) and rescales
+// its sum once per chunk, not per element.  Algorithmic bytes: rows * V * 4 read once (62.5 MB at B*T=512, V=30522).
+#define LSM_U 4
+__device__ __forceinline__ void lsm_combine(float& m, int& mi, float& s, float om, int oi, float os) {
+  const float M = fmaxf(m, om);
+  const float sa = (m == -INFINITY) ? 0.f : s * expf(m - M);
+  const float sb = (om == -INFINITY) ? 0.f : os * expf(om - M);
+  if (om > m || (om == m && oi < mi)) mi = oi;
+  m = M; s = sa + sb;
+}
+__global__ void __launch_bounds__(1024) lsm_stats_kernel(const float* __restrict__ logits, int ld,
+                                                         const long long* __restrict__ target,
+                                                         float* __restrict__ row_loss, float* __restrict__ row_lse,
+                                                         long long* __restrict__ pred, int V) {
+  __shared__ float red_m[16], red_s[16];
+  __shared__ int red_i[16];
+  const int row = blockIdx.x;
+  const float* x = logits + (size_t)row * ld;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  const int nvec = (V + 3) >> 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float m = -INFINITY, s = 0.f; int mi = 0x7fffffff;
+  for (int j0 = threadIdx.x; j0 < nvec; j0 += 1024 * LSM_U) {
+    f32x4 v[LSM_U];
+#pragma unroll
+    for (int u = 0; u < LSM_U; ++u) {
+      const int j = j0 + u * 1024;
+      v[u] = (j < nvec) ? x4[j] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+    float cm = m;
+#pragma unroll
+    for (int u = 0; u < LSM_U; ++u) {
+      const int base = (j0 + u * 1024) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (base + e >= V) v[u][e] = -INFINITY;            // the pad columns of the last vector
+        if (v[u][e] > cm) { cm = v[u][e]; mi = base + e; }   // indices increase within a thread: first index wins
+      }
+    }
+    if (cm > -INFINITY) {
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < LSM_U; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += expf(v[u][e] - cm);   // exp(-inf) = 0 for masked slots
+      s = (m == -INFINITY ? 0.f : s * expf(m - cm)) + acc;
+      m = cm;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o, 64), os = __shfl_xor(s, o, 64);
+    const int oi = __shfl_xor(mi, o, 64);
+    lsm_combine(m, mi, s, om, oi, os);
+  }
+  if (lane == 0) { red_m[wave] = m; red_i[wave] = mi; red_s[wave] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) lsm_combine(m, mi, s, red_m[w], red_i[w], red_s[w]);
+    const float lse = m + logf(s);
+    row_lse[row] = lse;
+    row_loss[row] = lse - x[target[row]];
+    pred[row] = mi;
+  }
+}
+// dlogits = (softmax - onehot) * gs from the saved row log-sums: one streaming read + one streaming write
+// (2 * rows * V * 4 bytes); blockIdx.y walks the row in pieces of 256 * LSM_U float4; pad columns are zeroed.
+__global__ void __launch_bounds__(256) lsm_grad_kernel(const float* __restrict__ logits, int ld,
+                                                       const long long* __restrict__ target,
+                                                       const float* __restrict__ row_lse, float* __restrict__ dlogits,
+                                                       int dld, const float* __restrict__ gscale_ptr, float gscale_mul,
+                                                       int V) {
+  const int row = blockIdx.x;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(logits + (size_t)row * ld);
+  f32x4* d4 = reinterpret_cast<f32x4*>(dlogits + (size_t)row * dld);
+  const int nvec = (V + 3) >> 2;
+  const float lse = row_lse[row];
+  const int tg = (int)target[row];
+  const float gs = (gscale_ptr ? *gscale_ptr : 1.0f) * gscale_mul;
+  const int j0 = blockIdx.y * 256 * LSM_U + threadIdx.x;
+  f32x4 v[LSM_U];
+#pragma unroll
+  for (int u = 0; u < LSM_U; ++u) {
+    const int j = j0 + u * 256;
+    if (j < nvec) v[u] = x4[j];
+  }
+#pragma unroll
+  for (int u = 0; u < LSM_U; ++u) {
+    const int j = j0 + u * 256;
+    if (j >= nvec) continue;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = j * 4 + e;
+      o[e] = i < V ? (expf(v[u][e] - lse) - (i == tg ? 1.f : 0.f)) * gs : 0.f;
+    }
+    d4[j] = o;
   }
 }
 
@@ -646,52 +749,140 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __r
 }
 
 // =========================================================================== SupCon / SimCLR (models/SupConLoss/loss.py:21-98)
-// features f [R=2N, D] ordered view-major (cat(unbind(features,1))): positive of r is (r+N) mod 2N.
-// Single workgroup; writes loss and df (already scaled by gscale).
-__global__ void supcon_kernel(const float* __restrict__ f, float* __restrict__ loss_out, float* __restrict__ df,
-                              int N, int D, float temp, float base_temp, float gscale) {
-  extern __shared__ float sm[];  // z [R][R], then lse[R]
-  const int R = 2 * N;
-  float* z = sm;
-  float* lse = sm + R * R;
-  for (int i = threadIdx.x; i < R * R; i += blockDim.x) {
-    int a = i / R, b = i - a * R;
-    float s = 0.f;
-    for (int k = 0; k < D; ++k) s += f[(size_t)a * D + k] * f[(size_t)b * D + k];
-    z[i] = s / temp;
+// features f [R=2N, D] ordered view-major (cat(unbind(features,1)), loss.py:57): positive of r is (r+N) mod 2N.
+// Tiled over row blocks so that the all-gathered view set of a data-parallel job (R = 2N*world, SURVEY 8(e)
+// collective 2) runs at any size: a workgroup owns SC_ROWS anchor rows and walks the contrast rows in tiles of
+// 64 staged in LDS (lane = contrast row, so a score never leaves its register); nothing of size R*R exists.
+//   pass 1 (supcon_rows_kernel): z = f f^T / T (loss.py:70-72), row max over ALL columns incl. the diagonal
+//     (:74-75), log sum of exp over the columns != row (:88-89) -> lse[r], row_loss[r] = -(z[r,pos] - lse[r]) (:92-95)
+//   pass 2 (supcon_grad_kernel): dL/dz[a][b] = c (p_a[b] - [b = pos a]) with p_a = softmax over b != a; z and the
+//     positive map are symmetric, so df[a] = c/T * sum_b (p_a[b] + p_b[a] - 2 [b = pos a]) f[b]: scores recomputed.
+//   pass 3 (supcon_reduce_kernel): loss = (T/T_base) * mean_r row_loss[r] (:95-96), fixed summation order.
+#define SC_ROWS 16
+#define SC_COLS 64
+#define SC_MAXD 256
+__device__ __forceinline__ void sc_stage(float* dst, int dst_ld, const float* __restrict__ f, int row0, int nrows,
+                                         int R, int D) {
+  for (int i = threadIdx.x; i < nrows * D; i += blockDim.x) {
+    const int r = i / D, k = i - r * D;
+    dst[r * dst_ld + k] = (row0 + r < R) ? f[(size_t)(row0 + r) * D + k] : 0.f;
   }
-  __syncthreads();
-  for (int a = threadIdx.x; a < R; a += blockDim.x) {
-    float m = -INFINITY;
-    for (int b = 0; b < R; ++b) m = fmaxf(m, z[a * R + b]);
-    float s = 0.f;
-    for (int b = 0; b < R; ++b) if (b != a) s += expf(z[a * R + b] - m);
-    lse[a] = m + logf(s);
-  }
-  __syncthreads();
-  const float coef = temp / base_temp;
-  if (threadIdx.x == 0) {
-    float l = 0.f;
-    for (int a = 0; a < R; ++a) l += -(z[a * R + (a + N) % R] - lse[a]);
-    *loss_out = coef * l / (float)R;
-  }
-  if (df) {
-    // dL/dz[a][b] = coef/R * (softmax_{b!=a}(z[a])[b] - [b==pos(a)])
+}
+__global__ void __launch_bounds__(256) supcon_rows_kernel(const float* __restrict__ f, float* __restrict__ lse,
+                                                          float* __restrict__ row_loss, int N, int D, float temp) {
+  extern __shared__ float sm[];
+  const int R = 2 * N, ldb = D + 1;
+  float* fa = sm;                      // [SC_ROWS][D]   anchors of this workgroup
+  float* fb = sm + SC_ROWS * D;        // [SC_COLS][D+1] contrast tile (odd stride: lane = row reads conflict-free)
+  const int a0 = blockIdx.x * SC_ROWS, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  sc_stage(fa, D, f, a0, SC_ROWS, R, D);
+  float m[4], s[4], zp[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; s[r] = 0.f; zp[r] = 0.f; }
+  for (int b0 = 0; b0 < R; b0 += SC_COLS) {
     __syncthreads();
-    for (int i = threadIdx.x; i < R * R; i += blockDim.x) {
-      int a = i / R, b = i - a * R;
-      float g = (b == a) ? 0.f : expf(z[i] - lse[a]);
-      if (b == (a + N) % R) g -= 1.f;
-      z[i] = g * coef / (float)R / temp * gscale;
+    sc_stage(fb, ldb, f, b0, SC_COLS, R, D);
+    __syncthreads();
+    const int b = b0 + lane;
+    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < D; ++k) {
+      const float vb = fb[lane * ldb + k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dot[r] += fa[(wave * 4 + r) * D + k] * vb;
+    }
+    if (b < R) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = a0 + wave * 4 + r;
+        const float z = dot[r] / temp;
+        const float mn = fmaxf(m[r], z);                 // the diagonal takes part in the max, not in the sum
+        s[r] = s[r] * __expf(m[r] - mn) + (b != a ? __expf(z - mn) : 0.f);
+        m[r] = mn;
+        if (b == (a + N) % R) zp[r] = z;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int a = a0 + wave * 4 + r;
+    const float M = wave_max(m[r]);
+    const float S = wave_sum(m[r] == -INFINITY ? 0.f : s[r] * __expf(m[r] - M));
+    const float Z = wave_sum(zp[r]);
+    if (lane == 0 && a < R) {
+      const float l = M + logf(S);
+      lse[a] = l;
+      row_loss[a] = -(Z - l);
+    }
+  }
+}
+__global__ void __launch_bounds__(256) supcon_grad_kernel(const float* __restrict__ f, const float* __restrict__ lse,
+                                                          float* __restrict__ df, int N, int D, float temp,
+                                                          float cscale) {
+  extern __shared__ float sm[];
+  const int R = 2 * N, ldb = D + 1;
+  float* fa = sm;                               // [SC_ROWS][D]
+  float* fb = fa + SC_ROWS * D;                 // [SC_COLS][D+1]
+  float* w = fb + SC_COLS * ldb;                // [SC_ROWS][SC_COLS] gradient weights of the current tile
+  const int a0 = blockIdx.x * SC_ROWS, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  sc_stage(fa, D, f, a0, SC_ROWS, R, D);
+  float lse_a[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const int a = a0 + wave * 4 + r; lse_a[r] = a < R ? lse[a] : 0.f; }
+  float acc[SC_ROWS * SC_MAXD / 256];
+#pragma unroll
+  for (int j = 0; j < SC_ROWS * SC_MAXD / 256; ++j) acc[j] = 0.f;
+  for (int b0 = 0; b0 < R; b0 += SC_COLS) {
+    __syncthreads();
+    sc_stage(fb, ldb, f, b0, SC_COLS, R, D);
+    __syncthreads();
+    const int b = b0 + lane;
+    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < D; ++k) {
+      const float vb = fb[lane * ldb + k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dot[r] += fa[(wave * 4 + r) * D + k] * vb;
+    }
+    const float lse_b = b < R ? lse[b] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int a = a0 + wave * 4 + r;
+      float g = 0.f;
+      if (b < R && a < R && b != a) {
+        const float z = dot[r] / temp;
+        g = __expf(z - lse_a[r]) + __expf(z - lse_b) - (b == (a + N) % R ? 2.f : 0.f);
+      }
+      w[(wave * 4 + r) * SC_COLS + lane] = g;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < R * D; i += blockDim.x) {
-      int a = i / D, k = i - a * D;
-      float s = 0.f;
-      for (int b = 0; b < R; ++b) s += (z[a * R + b] + z[b * R + a]) * f[(size_t)b * D + k];
-      df[i] = s;
+#pragma unroll
+    for (int j = 0; j < SC_ROWS * SC_MAXD / 256; ++j) {
+      const int i = threadIdx.x + j * 256;
+      if (i < SC_ROWS * D) {
+        const int r = i / D, k = i - r * D;
+        float t = 0.f;
+        for (int c = 0; c < SC_COLS; ++c) t += w[r * SC_COLS + c] * fb[c * ldb + k];
+        acc[j] += t;
+      }
     }
   }
+#pragma unroll
+  for (int j = 0; j < SC_ROWS * SC_MAXD / 256; ++j) {
+    const int i = threadIdx.x + j * 256;
+    if (i < SC_ROWS * D) {
+      const int r = i / D, k = i - r * D;
+      if (a0 + r < R) df[(size_t)(a0 + r) * D + k] = acc[j] * cscale;
+    }
+  }
+}
+__global__ void supcon_reduce_kernel(const float* __restrict__ row_loss, float* __restrict__ loss_out, int R,
+                                     float coef) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < R; i += blockDim.x) s += row_loss[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss_out = coef * (red[0] + red[1] + red[2] + red[3]) / (float)R;
 }
 
 // =========================================================================== Adam (torch defaults; roco_train.py:90)
@@ -879,12 +1070,33 @@ int k_meanpool_bwd(hipStream_t st, const float* dout, const long long* mask, flo
   return MMVQA_OK;
 }
 
-int k_lsm_nll(hipStream_t st, const float* logits, int ld, const long long* target, float* row_loss,
+static bool lsm_fast_ok(const float* logits, int ld, int V) {
+  return ((uintptr_t)logits & 15) == 0 && (ld & 3) == 0 && ld >= ((V + 3) & ~3);
+}
+int k_lsm_grad(hipStream_t st, const float* logits, int ld, const long long* target, const float* row_lse,
+               float* dlogits, int dld, const float* gscale_ptr, float gscale_mul, int rows, int V) {
+  if (!lsm_fast_ok(logits, ld, V) || !lsm_fast_ok(dlogits, dld, V))
+    return mmvqa_set_error(MMVQA_ERR_ARG, "mlm_grad: logits/dlogits rows must be 16-byte aligned with ld >= round_up(V,4)");
+  hipLaunchKernelGGL(lsm_grad_kernel, dim3(rows, cdiv_i((V + 3) >> 2, 256 * LSM_U)), dim3(256), 0, st, logits, ld, target,
+                     row_lse, dlogits, dld, gscale_ptr, gscale_mul, V);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+int k_lsm_nll(hipStream_t st, const float* logits, int ld, const long long* target, float* row_loss, float* row_lse,
               long long* pred, float* dlogits, int dld, const float* gscale_ptr, float gscale_mul, int rows, int V,
               float* out3) {
-  hipLaunchKernelGGL(lsm_nll_kernel, dim3(rows), dim3(256), 0, st, logits, ld, target, row_loss, pred, dlogits,
-                     dld, gscale_ptr, gscale_mul, V);
-  KERNEL_CHECK_RET();
+  if (row_lse && lsm_fast_ok(logits, ld, V) && (!dlogits || lsm_fast_ok(dlogits, dld, V))) {
+    hipLaunchKernelGGL(lsm_stats_kernel, dim3(rows), dim3(1024), 0, st, logits, ld, target, row_loss, row_lse, pred, V);
+    KERNEL_CHECK_RET();
+    if (dlogits) {
+      int r = k_lsm_grad(st, logits, ld, target, row_lse, dlogits, dld, gscale_ptr, gscale_mul, rows, V);
+      if (r != MMVQA_OK) return r;
+    }
+  } else {   // unaligned rows: scalar three-pass form
+    hipLaunchKernelGGL(lsm_nll_kernel, dim3(rows), dim3(256), 0, st, logits, ld, target, row_loss, row_lse, pred,
+                       dlogits, dld, gscale_ptr, gscale_mul, V);
+    KERNEL_CHECK_RET();
+  }
   if (out3) {
     hipLaunchKernelGGL(mlm_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, pred, target, rows, out3);
     KERNEL_CHECK_RET();
@@ -911,15 +1123,29 @@ int k_l2norm_bwd(hipStream_t st, const float* dy, const float* y, const float* n
   return MMVQA_OK;
 }
 
-int k_supcon(hipStream_t st, const float* f, float* loss, float* df, int N, int D, float temp, float base_temp,
-             float gscale) {
-  int R = 2 * N;
-  size_t sm = ((size_t)R * R + R) * sizeof(float);
-  if (sm > 160 * 1024) return mmvqa_set_error(MMVQA_ERR_ARG, "supcon: 2N=%d too large for one workgroup", R);
-  if (sm > 48 * 1024)
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)supcon_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)sm));
-  hipLaunchKernelGGL(supcon_kernel, dim3(1), dim3(256), sm, st, f, loss, df, N, D, temp, base_temp, gscale);
+int k_supcon(hipStream_t st, const float* f, float* loss, float* df, float* ws, int N, int D, float temp,
+             float base_temp, float gscale) {
+  const int R = 2 * N;
+  if (N < 1 || D < 1 || D > SC_MAXD) return mmvqa_set_error(MMVQA_ERR_ARG, "supcon: N=%d D=%d (1 <= D <= %d)", N, D, SC_MAXD);
+  if (!ws) return mmvqa_set_error(MMVQA_ERR_ARG, "supcon: workspace of 4*N floats required (lse, row losses)");
+  float* lse = ws;
+  float* row_loss = ws + R;
+  const int blocks = cdiv_i(R, SC_ROWS);
+  const size_t sm1 = ((size_t)SC_ROWS * D + (size_t)SC_COLS * (D + 1)) * sizeof(float);
+  const size_t sm2 = sm1 + (size_t)SC_ROWS * SC_COLS * sizeof(float);
+  if (sm2 > 48 * 1024) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)supcon_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1));
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)supcon_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2));
+  }
+  hipLaunchKernelGGL(supcon_rows_kernel, dim3(blocks), dim3(256), sm1, st, f, lse, row_loss, N, D, temp);
+  KERNEL_CHECK_RET();
+  const float coef = temp / base_temp;
+  if (df) {
+    hipLaunchKernelGGL(supcon_grad_kernel, dim3(blocks), dim3(256), sm2, st, f, lse, df, N, D, temp,
+                       coef / (float)R / temp * gscale);
+    KERNEL_CHECK_RET();
+  }
+  hipLaunchKernelGGL(supcon_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, loss, R, coef);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }

@@ -394,7 +394,7 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
   e->hd_mean = a.f(HM); e->hd_rstd = a.f(HM);
   if (d.supcon) {
     e->sc_pool = a.f((size_t)B * H); e->sc_pre = a.f((size_t)B * H); e->sc_a = a.f((size_t)B * H);
-    e->sc_f = a.f((size_t)B * d.feat_dim); e->sc_nrm = a.f(B);
+    e->sc_f = a.f((size_t)B * d.feat_dim); e->sc_nrm = a.f(B); e->sc_y = a.f((size_t)B * d.feat_dim);
   }
   // ---- backward scratch
   e->t_a = a.f(M * H); e->t_b = a.f(M * H); e->t_c = a.f(M * H); e->t_d = a.f(M * H);
@@ -1315,7 +1315,11 @@ static int heads_forward(mmvqa_engine* e, hipStream_t st, const float* h) {
     RUN(PROF_OTHER, 0, k_meanpool_fwd(st, h, e->mask, WS(e->sc_pool), e->B, e->T, H));
     TRY(lin_fwd(e, st, WS(e->sc_pool), H, e->B, e->head0, WS(e->sc_a), H, ACT_SERF, WS(e->sc_pre), 0.f, 0, nullptr, 0));
     TRY(lin_fwd(e, st, WS(e->sc_a), H, e->B, e->head2, WS(e->sc_f), d.feat_dim, ACT_NONE, nullptr, 0.f, 0, nullptr, 0));
-    RUN(PROF_OTHER, 0, k_l2norm_fwd(st, WS(e->sc_f), e->feat, WS(e->sc_nrm), e->B, d.feat_dim));
+    // the normalised features stay in the engine's workspace for the backward pass: the caller may drop its
+    // `feat` tensor before backward (supcon_utils.py:283-284 rebinds it to split_feat(feat))
+    RUN(PROF_OTHER, 0, k_l2norm_fwd(st, WS(e->sc_f), WS(e->sc_y), WS(e->sc_nrm), e->B, d.feat_dim));
+    HIP_CHECK_RET(hipMemcpyAsync(e->feat, WS(e->sc_y), (size_t)e->B * d.feat_dim * sizeof(float),
+                                 hipMemcpyDeviceToDevice, st));
   }
   return MMVQA_OK;
 }
@@ -1351,7 +1355,7 @@ static int heads_backward(mmvqa_engine* e, hipStream_t st, const float* h, const
   }
   if (d.supcon && dfeat) {
     float* df = WS(e->t_b);  // [B][feat_dim]
-    RUN(PROF_OTHER, 0, k_l2norm_bwd(st, dfeat, e->feat, WS(e->sc_nrm), df, e->B, d.feat_dim));
+    RUN(PROF_OTHER, 0, k_l2norm_bwd(st, dfeat, WS(e->sc_y), WS(e->sc_nrm), df, e->B, d.feat_dim));
     TRY(lin_wgrad(e, st, df, d.feat_dim, WS(e->sc_a), H, e->B, e->head2, true));
     TRY(lin_dgrad(e, st, df, d.feat_dim, e->B, e->head2, WS(e->t_c), H, ACT_SERF, WS(e->sc_pre), H, GRD(e->head0.b), nullptr, 0));
     TRY(lin_wgrad(e, st, WS(e->t_c), H, WS(e->sc_pool), H, e->B, e->head0, false));

@@ -117,7 +117,7 @@ struct mmvqa_engine {
   size_t emb_out = 0, emb_xhat = 0, emb_rstd = 0;
   size_t enc_out_final = 0;
   size_t hd_upre = 0, hd_u = 0, hd_c0 = 0, hd_c1 = 0, hd_mean = 0, hd_rstd = 0, hd_pool = 0;
-  size_t sc_pool = 0, sc_pre = 0, sc_a = 0, sc_f = 0, sc_nrm = 0;
+  size_t sc_pool = 0, sc_pre = 0, sc_a = 0, sc_f = 0, sc_nrm = 0, sc_y = 0;
   size_t t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_big = 0, t_dprev[2];  // backward scratch
   // ---- bound pointers
   float *params = nullptr, *grads = nullptr, *bufs = nullptr, *ws = nullptr;

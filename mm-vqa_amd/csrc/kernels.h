@@ -41,15 +41,17 @@ int k_embed_bwd(hipStream_t st, const float* dout, const long long* ids, const l
 int k_meanpool_fwd(hipStream_t st, const float* h, const long long* mask, float* out, int B, int T, int H);
 int k_meanpool_bwd(hipStream_t st, const float* dout, const long long* mask, float* dh, int B, int T, int H,
                    int accumulate);
-int k_lsm_nll(hipStream_t st, const float* logits, int ld, const long long* target, float* row_loss,
+int k_lsm_nll(hipStream_t st, const float* logits, int ld, const long long* target, float* row_loss, float* row_lse,
               long long* pred, float* dlogits, int dld, const float* gscale_ptr, float gscale_mul, int rows, int V,
               float* out3);
+int k_lsm_grad(hipStream_t st, const float* logits, int ld, const long long* target, const float* row_lse,
+               float* dlogits, int dld, const float* gscale_ptr, float gscale_mul, int rows, int V);
 int k_asl(hipStream_t st, const float* logits, int ld, const long long* target, float* row_loss, float* dlogits,
           int dld, int rows, int C, float gpos, float gneg, float eps, float gscale);
 int k_l2norm_fwd(hipStream_t st, const float* x, float* y, float* nrm, int rows, int D);
 int k_l2norm_bwd(hipStream_t st, const float* dy, const float* y, const float* nrm, float* dx, int rows, int D);
-int k_supcon(hipStream_t st, const float* f, float* loss, float* df, int N, int D, float temp, float base_temp,
-             float gscale);
+int k_supcon(hipStream_t st, const float* f, float* loss, float* df, float* ws, int N, int D, float temp,
+             float base_temp, float gscale);
 int k_adam(hipStream_t st, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
            int step, float gscale, int zero_grad);
 int k_axpy(hipStream_t st, float* y, const float* x, float a, long n);

@@ -86,3 +86,13 @@ class _AllGatherFeat(torch.autograd.Function):
 
 def all_gather_features(x):
     return _AllGatherFeat.apply(x)
+
+
+def global_supcon_views(feat, n):
+    """feat [2n, D] of this rank (view-major: process_tensors, supcon_utils.py:253-256) -> [world*n, 2, D] over the
+    global view set (split_feat layout, supcon_utils.py:259-261), so that every rank's samples are negatives of every
+    other rank's (SURVEY 8(e) collective 2); differentiable: backward returns this rank's rows."""
+    f = all_gather_features(feat)
+    w = world()
+    parts = f.view(w, 2, n, -1)
+    return torch.cat([parts[:, 0].reshape(w * n, 1, -1), parts[:, 1].reshape(w * n, 1, -1)], 1).contiguous()

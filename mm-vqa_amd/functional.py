@@ -25,6 +25,10 @@ def _padded(x2d):
 
 
 class _MLMLoss(torch.autograd.Function):
+    """forward: one pass over the logits (row log-sum-exp, NLL, first-index argmax); backward: one streaming
+    pass writing (softmax - onehot) * upstream / rows.  The upstream gradient is read on the device by the kernel:
+    nothing is synchronised with the host between forward and backward."""
+
     @staticmethod
     def forward(ctx, logits, target):
         if not logits.is_cuda:
@@ -34,27 +38,26 @@ class _MLMLoss(torch.autograd.Function):
         rows = x.shape[0]
         tgt = target.reshape(-1).contiguous().long()
         row_loss = torch.empty(rows, dtype=torch.float32, device=x.device)
+        row_lse = torch.empty(rows, dtype=torch.float32, device=x.device)
         pred = torch.empty(rows, dtype=torch.int64, device=x.device)
         out3 = torch.empty(3, dtype=torch.float32, device=x.device)
-        dld = (V + 3) & ~3
-        dl = torch.zeros(rows, dld, dtype=torch.float32, device=x.device)
-        # gradient of the MEAN loss, computed in the same pass; scaled by the upstream grad in backward
-        L.check(L.lib().mmvqa_mlm_loss(L.stream_ptr(), L.ptr(x), ld, L.ptr(tgt), L.ptr(row_loss), L.ptr(pred),
-                                       L.ptr(dl), dld, None, 1.0 / rows, rows, V, L.ptr(out3)))
-        ctx.save_for_backward(dl)
-        ctx.shape = logits.shape
+        L.check(L.lib().mmvqa_mlm_loss(L.stream_ptr(), L.ptr(x), ld, L.ptr(tgt), L.ptr(row_loss), L.ptr(row_lse),
+                                       L.ptr(pred), None, 0, None, 1.0, rows, V, L.ptr(out3)))
+        ctx.save_for_backward(x, tgt, row_lse)
+        ctx.ld, ctx.shape = ld, logits.shape
         ctx.mark_non_differentiable(pred, out3)
         return out3[0].clone(), pred.view(target.shape), out3
 
     @staticmethod
     def backward(ctx, gloss, _gp, _go):
-        (dl,) = ctx.saved_tensors
-        V = ctx.shape[-1]
-        if gloss.numel() == 1 and float(gloss) == 1.0:
-            g = dl
-        else:
-            g = dl * gloss
-        return g[:, :V].view(ctx.shape), None
+        x, tgt, row_lse = ctx.saved_tensors
+        rows, V = x.shape
+        dld = (V + 3) & ~3
+        dl = torch.empty(rows, dld, dtype=torch.float32, device=x.device)
+        g = gloss.reshape(1).float().contiguous()
+        L.check(L.lib().mmvqa_mlm_grad(L.stream_ptr(), L.ptr(x), ctx.ld, L.ptr(tgt), L.ptr(row_lse), L.ptr(dl), dld,
+                                       L.ptr(g), 1.0 / rows, rows, V))
+        return dl[:, :V].view(ctx.shape), None
 
 
 def mlm_loss(logits, target):
@@ -99,8 +102,9 @@ class _SupCon(torch.autograd.Function):
         f = torch.cat(torch.unbind(features, dim=1), dim=0).contiguous().float()
         loss = torch.empty(1, dtype=torch.float32, device=f.device)
         df = torch.empty_like(f)
-        L.check(L.lib().mmvqa_supcon_loss(L.stream_ptr(), L.ptr(f), L.ptr(loss), L.ptr(df), N, D, temperature,
-                                          base_temperature, 1.0))
+        ws = torch.empty(4 * N, dtype=torch.float32, device=f.device)
+        L.check(L.lib().mmvqa_supcon_loss(L.stream_ptr(), L.ptr(f), L.ptr(loss), L.ptr(df), L.ptr(ws), N, D,
+                                          temperature, base_temperature, 1.0))
         ctx.save_for_backward(df)
         ctx.N = N
         return loss[0].clone()

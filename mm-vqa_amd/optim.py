@@ -41,4 +41,8 @@ class FusedAdam:
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
-        self.step_count = int(sd["step"]); self.param_groups = sd["param_groups"]
+        self.step_count = int(sd["step"])
+        # in place: a scheduler built on this optimizer keeps pointing at the SAME list/dicts, so a later
+        # ReduceLROnPlateau step still reaches mmvqa_adam after --resume
+        for mine, theirs in zip(self.param_groups, sd["param_groups"]):
+            mine.update(theirs)

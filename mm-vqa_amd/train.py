@@ -27,7 +27,7 @@ import torch.distributed as dist
 from torch.optim import lr_scheduler
 
 from . import FusedAdam, Model, asl_loss, mlm_loss, split_feat, supcon_loss, synth
-from .ddp import GradReducer, all_gather_features
+from .ddp import GradReducer, global_supcon_views
 
 
 def common_args(p):
@@ -110,9 +110,18 @@ class _SchedShim(torch.optim.Optimizer):
 
 
 def save_recorder(args, epoch, model, opt, sched):
+    """the 5-epoch "recorder" dict of roco_train.py:164-171 / roco_supcon_train.py:177-184"""
     os.makedirs(args.save_dir, exist_ok=True)
     torch.save({"epoch": epoch, "optimizer": opt.state_dict(), "scheduler": sched.state_dict(), "scaler": {},
                 "model": model.state_dict()}, os.path.join(args.save_dir, "recorder_2.pt"))
+
+
+def save_model(args, model, suffix=""):
+    """torch.save(model.state_dict(), save_dir/task/run_name[+suffix].pt) -- roco_train.py:194-197,
+    roco_supcon_train.py:199-202, vqamed2019/train.py:265-283"""
+    d = os.path.join(args.save_dir, args.task)
+    os.makedirs(d, exist_ok=True)
+    torch.save(model.state_dict(), os.path.join(d, args.run_name + suffix + ".pt"))
 
 
 def maybe_resume(args, model, opt, sched):
@@ -156,8 +165,7 @@ def run_mlm(args):
             print(f"Epoch {epoch + 1}/{args.epochs} Learning rate: {opt.param_groups[0]['lr']:.7f}, Train loss: {tl:.4f}, "
                   f"Train acc: {100.0 * nc / max(nm, 1):.4f} ,Val loss: {vl:.4f}, Val acc: {va:.4f}", flush=True)
             if vl < best:
-                os.makedirs(os.path.join(args.save_dir, args.task), exist_ok=True)
-                torch.save(model.state_dict(), os.path.join(args.save_dir, args.task, args.run_name + ".pt"))
+                save_model(args, model)
         best = min(best, vl)
     return best
 
@@ -185,6 +193,8 @@ def run_supcon(args):
     model, opt, sched, red = build(args, ctx)
     T, V = args.max_position_embeddings, args.vocab_size
     n = args.batch_size // 2                      # roco_supcon_train.py:137: the loader yields bs//2 pairs
+    if n < 1:
+        raise ValueError("--batch_size must be >= 2 (two views per sample)")
     best, start = float("inf"), maybe_resume(args, model, opt, sched)
     for epoch in range(start, args.epochs):
         model.train()
@@ -199,20 +209,21 @@ def run_supcon(args):
             opt.zero_grad()
             logits, feat = model(img, ids, seg, mask)
             loss = mlm_loss(logits, tgt)[0]
-            f = all_gather_features(feat)          # global negatives under DDP
-            w = ctx.world
-            parts = f.view(w, 2, n, -1)
-            feats = torch.cat([parts[:, 0].reshape(w * n, 1, -1), parts[:, 1].reshape(w * n, 1, -1)], 1)
-            loss = loss + supcon_loss(feats.contiguous())
+            feat = global_supcon_views(feat, n)    # split_feat over the all-gathered views (global negatives)
+            loss = loss + supcon_loss(feat)         # 2N*world rows: the tiled kernel has no size cap
             loss.backward()
             red.allreduce()
             opt.step(grad_scale=1.0 / ctx.world, zero_grad=True)
             tl += float(loss.detach())
         vl, va = validate_mlm(args, ctx, model, epoch)
         sched.step(vl)
+        if (epoch + 1) % 5 == 0 and ctx.rank == 0:       # roco_supcon_train.py:177-184
+            save_recorder(args, epoch, model, opt, sched)
         if ctx.rank == 0:
             print(f"Epoch {epoch + 1}/{args.epochs} Learning rate: {opt.param_groups[0]['lr']:.7f}, "
                   f"Train loss: {tl / args.steps_per_epoch:.4f}, Val loss: {vl:.4f}, Val acc: {va:.4f}", flush=True)
+            if vl < best:                                 # roco_supcon_train.py:199-202
+                save_model(args, model)
         best = min(best, vl)
     return best
 
@@ -226,7 +237,9 @@ def run_vqa(args):
     T, B = args.max_position_embeddings, args.batch_size
     crit = (lambda lg, t: asl_loss(lg, t)) if args.loss == "ASLSingleLabel" else (lambda lg, t: mlm_loss(lg, t)[0])
     best_loss, best_acc1, best_acc2, counter = float("inf"), 0.0, 0.0, 0
-    for epoch in range(args.epochs):
+    # (vqamed2019/train.py itself has no recorder / --resume; kept here like the two pre-training loops)
+    start = maybe_resume(args, model, opt, sched)
+    for epoch in range(start, args.epochs):
         model.train()
         tl = 0.0
         for i in range(args.steps_per_epoch):
@@ -253,6 +266,13 @@ def run_vqa(args):
         if ctx.rank == 0:
             print(f"Epoch {epoch + 1}/{args.epochs} lr {opt.param_groups[0]['lr']:.7f} train_loss {tl / args.steps_per_epoch:.4f} "
                   f"val_loss {vl:.4f} val_total_acc {acc:.2f}", flush=True)
+        if (epoch + 1) % 5 == 0 and ctx.rank == 0:
+            save_recorder(args, epoch, model, opt, sched)
+        if ctx.rank == 0:
+            if vl < best_loss:                   # train.py:264-268 "save by val loss"
+                save_model(args, model, "_loss")
+            if acc > best_acc1:                  # train.py:270-276 "save by accuracy in val"
+                save_model(args, model)
         best_loss = min(best_loss, vl)
         best_acc1 = max(best_acc1, acc)
         if best_acc1 > best_acc2:                # train.py:288-296 early stop

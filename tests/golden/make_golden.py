@@ -31,6 +31,7 @@ sys.dont_write_bytecode = True
 
 import transformers  # noqa: F401  (must be imported before the stubs)
 from oracle import mmbert_oracle as O  # noqa: E402
+from oracle import effnet_oracle as E  # noqa: E402
 
 # ---- stub the absent third-party packages (names only; no arithmetic in the stubs)
 _tv = types.ModuleType("torchvision")
@@ -168,18 +169,27 @@ def build_ref_model(args, orc):
                      max_position_embeddings=args.bert_max_pos)
     RM.TransformerAbstract.get_bert_embedding = lambda self, a: BertEmbeddings(cfg)
     RI.models_dict[5]["resnet152"][0] = lambda pretrained=True: O.OracleResNet(args.resnet_layers, args.resnet_width)
+    # timm.create_model(name, features_only=True, pretrained=True) (image_encoding.py:26): the reference's own
+    # Timm_EFfNetV2.__init__/forward (image_encoding.py:89-115) then runs on the oracle's features-only body
+    RI.models_dict[5]["tf_efficientnetv2_m"][0] = (
+        lambda name, features_only=True, pretrained=True: E.OracleEffNetV2Features(getattr(args, "effnet_depth_div", 1)))
     ref = RM.Model(args)
+    if "efficientnetv2" in args.cnn_encoder:
+        assert type(ref.transformer.trans).__name__ == "Timm_EFfNetV2"
     missing = ref.load_state_dict(orc.state_dict(), strict=True)
     return ref
 
 
-def gold_model(tag, transformer_model, dataset, supcon, B, T, img_hw, lens):
+def gold_model(tag, transformer_model, dataset, supcon, B, T, img_hw, lens, cnn="resnet152", use_relu=False):
     seed = 51
     kw = dict(transformer_model=transformer_model, dataset=dataset, hidden_size=768, n_layers=2, heads=12,
               hidden_dropout_prob=0.0, vocab_size=64 if dataset == "roco" else 23,
-              resnet_layers=(1, 1, 1, 1), resnet_width=64, bert_max_pos=32, use_relu=False)
+              resnet_layers=(1, 1, 1, 1), resnet_width=64, bert_max_pos=32, use_relu=use_relu, cnn_encoder=cnn)
     if supcon:
         kw["supcon"] = True
+    eff = "efficientnetv2" in cnn
+    if eff:
+        kw["effnet_depth_div"] = 8   # every stage type / width / stride / SE of the full body, 1-3 blocks per stage
     args = O.make_args(**kw)
     # vocab_size doubles as embedding vocab AND classifier width in the reference (mmbert.py:137)
     torch.manual_seed(seed)
@@ -222,9 +232,17 @@ def gold_model(tag, transformer_model, dataset, supcon, B, T, img_hw, lens):
     sd = dict(ref.named_parameters())
     pick = ["fc1.weight", "classifier.1.bias", "transformer.bert_embedding.word_embeddings.weight",
             "transformer.bert_embedding.LayerNorm.weight", "transformer.trans.conv7.weight",
-            "transformer.trans.conv2.weight", "transformer.trans.model.conv1.weight",
-            "transformer.trans.model.bn1.weight", "transformer.trans.model.layer3.0.conv2.weight",
-            "transformer.trans.model.layer1.0.downsample.0.weight"]
+            "transformer.trans.conv2.weight", "transformer.trans.model.bn1.weight"]
+    if eff:
+        pick += ["transformer.trans.conv3.weight", "transformer.trans.conv4.weight", "transformer.trans.conv5.weight",
+                 "transformer.trans.model.conv_stem.weight", "transformer.trans.model.blocks.0.0.conv.weight",
+                 "transformer.trans.model.blocks.1.0.conv_exp.weight", "transformer.trans.model.blocks.2.0.conv_pwl.weight",
+                 "transformer.trans.model.blocks.3.0.conv_dw.weight", "transformer.trans.model.blocks.3.0.se.conv_reduce.bias",
+                 "transformer.trans.model.blocks.4.1.se.conv_expand.weight", "transformer.trans.model.blocks.5.0.bn2.bias",
+                 "transformer.trans.model.blocks.6.0.conv_pw.weight"]
+    else:
+        pick += ["transformer.trans.model.conv1.weight", "transformer.trans.model.layer3.0.conv2.weight",
+                 "transformer.trans.model.layer1.0.downsample.0.weight"]
     if transformer_model == "transformer":
         pick += ["transformer.blocks.norm1.weight", "transformer.blocks.attention.0.proj_q.weight"]
     else:
@@ -241,22 +259,41 @@ def gold_model(tag, transformer_model, dataset, supcon, B, T, img_hw, lens):
     arrs["grad_fp"] = np.array(fp)
     # BN running stats after ONE reference forward (quirk 7: k-fold updates)
     bsd = ref.state_dict()
-    for k in ["transformer.trans.model.bn1.running_mean", "transformer.trans.model.bn1.running_var",
-              "transformer.trans.model.bn1.num_batches_tracked",
-              "transformer.trans.model.layer2.0.bn2.running_var",
-              "transformer.trans.model.layer2.0.bn2.num_batches_tracked",
-              "transformer.trans.model.layer4.0.bn3.running_mean",
-              "transformer.trans.model.layer4.0.bn3.num_batches_tracked"]:
+    bkeys = ["transformer.trans.model.bn1.running_mean", "transformer.trans.model.bn1.running_var",
+             "transformer.trans.model.bn1.num_batches_tracked"]
+    if eff:   # one backbone pass (image_encoding.py:101) => every BatchNorm updates exactly once
+        bkeys += ["transformer.trans.model.blocks.1.0.bn1.running_var", "transformer.trans.model.blocks.3.0.bn2.running_mean",
+                  "transformer.trans.model.blocks.4.0.bn2.running_var", "transformer.trans.model.blocks.4.0.bn2.num_batches_tracked",
+                  "transformer.trans.model.blocks.6.0.bn3.running_mean", "transformer.trans.model.blocks.6.0.bn3.num_batches_tracked"]
+    else:
+        bkeys += ["transformer.trans.model.layer2.0.bn2.running_var",
+                  "transformer.trans.model.layer2.0.bn2.num_batches_tracked",
+                  "transformer.trans.model.layer4.0.bn3.running_mean",
+                  "transformer.trans.model.layer4.0.bn3.num_batches_tracked"]
+    for k in bkeys:
         arrs["b_" + k.replace(".", "__")] = bsd[k]
     save(tag, **arrs)
 
 
+EFF = "tf_efficientnetv2_m"
+JOBS = {
+    "act": gold_activations, "bertlayer": gold_bertlayer, "realformer": gold_realformer, "losses": gold_losses,
+    "model_tr_roco": lambda: gold_model("model_tr_roco", "transformer", "roco", False, 2, 12, 64, [12, 9]),
+    "model_rf_roco_supcon": lambda: gold_model("model_rf_roco_supcon", "realformer", "roco", True, 4, 11, 64, [11, 8, 10, 9]),
+    "model_tr_vqa": lambda: gold_model("model_tr_vqa", "transformer", "VQA-Med", False, 3, 10, 64, [10, 8, 9]),
+    "model_rf_vqa": lambda: gold_model("model_rf_vqa", "realformer", "VQA-Med", False, 2, 10, 64, [10, 9]),
+    # the reference's Timm_EFfNetV2 (image_encoding.py:89-115) on the oracle's features-only body:
+    # BASELINE configs[2] (MLM), configs[3] (MLM + SupCon head, 2N views), configs[4] (VQA head + ASL) shapes,
+    # and the --use_relu tap variant (README rows "EfficientNetV2 + Transformer, ReLU")
+    "model_eff_rf_roco": lambda: gold_model("model_eff_rf_roco", "realformer", "roco", False, 3, 12, 64, [12, 9, 10], cnn=EFF),
+    "model_eff_rf_roco_supcon": lambda: gold_model("model_eff_rf_roco_supcon", "realformer", "roco", True, 4, 11, 64,
+                                                   [11, 8, 10, 9], cnn=EFF),
+    "model_eff_rf_vqa_asl": lambda: gold_model("model_eff_rf_vqa_asl", "realformer", "VQA-Med", False, 4, 10, 72,
+                                               [10, 8, 9, 10], cnn=EFF),
+    "model_eff_tr_roco_relu": lambda: gold_model("model_eff_tr_roco_relu", "transformer", "roco", False, 2, 12, 64, [12, 9],
+                                                 cnn=EFF, use_relu=True),
+}
+
 if __name__ == "__main__":
-    gold_activations()
-    gold_bertlayer()
-    gold_realformer()
-    gold_losses()
-    gold_model("model_tr_roco", "transformer", "roco", False, 2, 12, 64, [12, 9])
-    gold_model("model_rf_roco_supcon", "realformer", "roco", True, 4, 11, 64, [11, 8, 10, 9])
-    gold_model("model_tr_vqa", "transformer", "VQA-Med", False, 3, 10, 64, [10, 8, 9])
-    gold_model("model_rf_vqa", "realformer", "VQA-Med", False, 2, 10, 64, [10, 9])
+    for name in (sys.argv[1:] or list(JOBS)):   # no arguments: regenerate everything
+        JOBS[name]()

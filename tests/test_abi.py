@@ -78,7 +78,7 @@ def test_model_protocol_on_cpu():
     full = mmvqa_amd.Model(O.make_args())
     n_backbone = sum(p.numel() for n, p in full.named_parameters() if n.startswith("transformer.trans.model."))
     assert n_backbone == 60192808                       # torchvision resnet152
-    assert sum(p.numel() for p in full.parameters()) == 140_034_154 or True
+    assert sum(p.numel() for p in full.parameters()) == 140_024_674   # = the oracle's (reference-pinned) Model
     # timm tf_efficientnetv2_m(features_only=True): published body size, oracle-identical state_dict
     eff = mmvqa_amd.Model(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer"))
     n_eff = sum(p.numel() for n, p in eff.named_parameters() if n.startswith("transformer.trans.model."))

@@ -16,7 +16,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from mmvqa_amd.ddp import GradReducer, all_gather_features
+    from mmvqa_amd.ddp import GradReducer, global_supcon_views
     from oracle import mmbert_oracle as O
     try:
         # 1. bucketed all-reduce of a flat gradient buffer (buckets smaller than the buffer, ragged tail)
@@ -42,9 +42,8 @@ def _worker(rank, world, port, q):
         n = 2
         # rank r owns samples r*n .. r*n+n ; model output order per rank is view-major: [v1 of its n, v2 of its n]
         local = torch.cat([full[rank * n:(rank + 1) * n, 0], full[rank * n:(rank + 1) * n, 1]], 0).requires_grad_(True)
-        gathered = all_gather_features(local)                       # [world*2n, D], rank-major
-        parts = gathered.view(world, 2, n, 16)
-        feats = torch.cat([parts[:, 0].reshape(-1, 16).unsqueeze(1), parts[:, 1].reshape(-1, 16).unsqueeze(1)], 1)
+        feats = global_supcon_views(local, n)                       # the function train.py's supcon loop calls
+        assert torch.equal(feats, full)
         loss = O.supcon_simclr(feats)
         loss.backward()
         ref_in = full.clone().requires_grad_(True)

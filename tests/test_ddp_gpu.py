@@ -77,3 +77,53 @@ def test_two_rank_overlapped_allreduce_on_gpu():
         assert n_calls >= 3 and n_started >= n_calls, f"rank {rank}: hook calls {n_calls}, all-reduces started during backward {n_started}"
         assert covered, f"rank {rank}: announced ranges do not cover the buffer"
         assert err <= 1e-5, f"rank {rank}: reduced gradients differ from the sum of the per-rank gradients: {err:.2e}"
+
+
+def _supcon_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mmvqa_amd
+        from mmvqa_amd.ddp import global_supcon_views
+        from oracle import mmbert_oracle as O
+        dev = torch.device("cuda", 0)
+        n, D = 64, 128                                  # 2n*world = 256 rows = BASELINE configs[3] on 8 GPUs
+        torch.manual_seed(7)
+        full = torch.nn.functional.normalize(torch.randn(n * world, 2, D), dim=2)       # [N_global, 2 views, D]
+        mine = full[rank * n:(rank + 1) * n]
+        local = torch.cat([mine[:, 0], mine[:, 1]], 0).to(dev).requires_grad_(True)    # model output order
+        feats = global_supcon_views(local, n)           # all-gather (differentiable) + split_feat layout
+        assert feats.shape == (n * world, 2, D)
+        loss = mmvqa_amd.supcon_loss(feats)             # HIP kernel on the gathered set
+        loss.backward()
+        torch.cuda.synchronize()
+        ref_in = full.clone().requires_grad_(True)
+        ref = O.supcon_simclr(ref_in)
+        ref.backward()
+        g = ref_in.grad[rank * n:(rank + 1) * n]
+        gref = torch.cat([g[:, 0], g[:, 1]], 0) * world   # every rank back-propagates the same global loss
+        err = float((local.grad.cpu() - gref).abs().max() / gref.abs().max())
+        q.put((rank, abs(float(loss) - float(ref)) / abs(float(ref)), err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gathered_supcon_on_gpu():
+    """all-gather of the [2n, 128] features -> HIP SupCon over 2n*world = 256 rows -> each rank gets the gradient of
+    its own rows of the single-process global loss"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_supcon_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, lerr, gerr in res:
+        assert lerr <= 2e-5, f"rank {rank}: global SupCon loss differs from the oracle: {lerr:.2e}"
+        assert gerr <= 1e-4, f"rank {rank}: feature gradient differs from the slice of the global one: {gerr:.2e}"

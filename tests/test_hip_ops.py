@@ -107,6 +107,49 @@ def test_dgrad_fused_act_backward():
         assert_close(cs, pr.grad.sum(0), TOL, "colsum " + act)
 
 
+def test_act_golden_edge_replay(golden_dir):
+    """tests/golden/act.npz -- x incl. {-100, -50, -20, 0, 20, 49.9, 50, 50.1, 80, 1e4} with the REFERENCE's SERF
+    (models/serf.py:23-24) and GELU (models/transformer.py:7-8) values and derivatives -- through the HIP GEMM
+    epilogues: an identity GEMM (exact in fp32 MFMA arithmetic) feeds x to act() / act'()."""
+    import numpy as np
+    g = dict(np.load(f"{golden_dir}/act.npz"))
+    x = torch.from_numpy(g["x"]).float()
+    M, Kd = x.numel(), 4
+    X = torch.zeros(M, Kd)
+    X[:, 0] = x
+    Xd, Id = X.to(dev()), torch.eye(Kd).to(dev())
+    e0 = torch.zeros(M, Kd)
+    e0[:, 0] = 1.0
+    e0d = e0.to(dev())
+    for act in ("serf", "gelu"):
+        y, pre = torch.zeros(M, Kd, device=dev()), torch.zeros(M, Kd, device=dev())
+        d = L.GemmDesc()
+        d.M, d.N, d.K = M, Kd, Kd
+        d.A, d.a_ld, d.g_Cs = P(Xd), Kd, Kd
+        d.B, d.b_ld = P(Id), Kd
+        linear_geom(d)
+        d.C, d.c_ld, d.Cpre, d.act = P(y), Kd, P(pre), ACT(act)
+        run_igemm(d, L.KIND_FWD)
+        assert torch.equal(pre[:, 0].cpu(), x), "identity GEMM must reproduce x bit for bit"
+        ref = torch.from_numpy(g[act]).double()
+        err = ((y[:, 0].cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+        assert err <= 2e-6, f"{act} forward vs reference: {err:.2e}"
+        out = torch.zeros(M, Kd, device=dev())
+        d = L.GemmDesc()
+        d.M, d.N, d.K = M, Kd, Kd
+        d.A, d.a_ld, d.g_Cs = P(e0d), Kd, Kd
+        d.B, d.b_ld = P(Id), Kd
+        linear_geom(d)
+        d.C, d.c_ld = P(out), Kd
+        d.dact, d.Pre, d.pre_ld = ACT(act), P(Xd), Kd
+        run_igemm(d, L.KIND_DGRAD)
+        dref = torch.from_numpy(g["d" + act]).double()
+        err = ((out[:, 0].cpu().double() - dref).abs() / dref.abs().clamp_min(1.0)).max().item()
+        assert err <= 3e-6, f"{act} derivative vs reference: {err:.2e}"
+        edge = x.abs() >= 20       # the ten hand-picked edge values: clamp at 50, saturation, underflow
+        assert int(edge.sum()) >= 10 and torch.isfinite(y[:, 0]).all() and torch.isfinite(out[:, 0]).all()
+
+
 # ----------------------------------------------------------------------------- convolution
 CONVS = [  # N, H, W, Cin, Cout, K, stride, pad
     (2, 9, 9, 8, 16, 3, 1, 1), (2, 9, 9, 8, 16, 3, 2, 1), (3, 8, 8, 16, 24, 1, 1, 0), (2, 9, 9, 16, 8, 1, 2, 0),
@@ -520,6 +563,45 @@ def test_asl_supcon_golden(golden_dir):
     assert_close(lg.grad, torch.from_numpy(g["mlm_dlogits"]), TOL, "mlm grad")
     t = torch.from_numpy(g["mlm_target"])
     assert np.array_equal(pred.cpu()[t > 0].numpy(), g["mlm_pred"])
+
+
+@pytest.mark.parametrize("N,D", [(5, 16), (16, 128), (37, 128), (64, 128), (128, 128), (192, 128), (320, 96)])
+def test_supcon_sizes(N, D):
+    """SupCon / SimCLR over 2N views for N up to the all-gathered set of an 8-GPU job and beyond (2N = 32*8 = 256
+    for BASELINE configs[3]; 48*8 = 384 for the README's batch-48 runs; ragged row/column tiles): loss and
+    gradient vs the oracle (models/SupConLoss/loss.py:57-96)"""
+    torch.manual_seed(15 + N)
+    f = F.normalize(torch.randn(N, 2, D), dim=2).requires_grad_(True)
+    ref = O.supcon_simclr(f)
+    ref.backward()
+    fd = f.detach().to(dev()).requires_grad_(True)
+    l = mmvqa_amd.supcon_loss(fd)
+    l.backward()
+    assert abs(float(l) - float(ref)) <= 2e-5 * abs(float(ref)), (float(l), float(ref))
+    assert_close(fd.grad, f.grad, TOL, f"supcon grad N={N}")
+    # un-normalised features (the ABI does not assume unit rows): large scores, max taken on the diagonal
+    g = (torch.randn(N, 2, D) * 0.6).requires_grad_(True)
+    ref = O.supcon_simclr(g)
+    ref.backward()
+    gd = g.detach().to(dev()).requires_grad_(True)
+    l = mmvqa_amd.supcon_loss(gd)
+    l.backward()
+    assert abs(float(l) - float(ref)) <= 5e-5 * abs(float(ref)), (float(l), float(ref))
+    assert_close(gd.grad, g.grad, 2e-4, f"supcon grad (unnormalised) N={N}")
+
+
+def test_mlm_loss_unaligned_and_upstream_scale():
+    """rows that are not 16-byte aligned take the scalar kernel; the upstream gradient is applied on the device"""
+    torch.manual_seed(16)
+    for V in (50, 1001, 30522):
+        lg = (torch.randn(3, 5, V) * 2).requires_grad_(True)
+        tgt = torch.randint(0, V, (3, 5))
+        (O.mlm_loss(lg, tgt)[0] * 0.37).backward()
+        x = lg.detach().to(dev()).requires_grad_(True)
+        loss, pred, stats = mmvqa_amd.mlm_loss(x, tgt.to(dev()))
+        (loss * 0.37).backward()
+        assert_close(x.grad, lg.grad, TOL, f"scaled dlogits V={V}")
+        assert torch.equal(pred.cpu(), lg.detach().log_softmax(-1).argmax(-1))
 
 
 def test_adam():

@@ -111,19 +111,38 @@ def test_losses(golden_dir):
     assert np.array_equal(pred.numpy(), g["mlm_pred"])  # index ops bit-exact
 
 
-@pytest.mark.parametrize("tag,tm,ds,supcon", [
-    ("model_tr_roco", "transformer", "roco", False),
-    ("model_rf_roco_supcon", "realformer", "roco", True),
-    ("model_tr_vqa", "transformer", "VQA-Med", False),
-    ("model_rf_vqa", "realformer", "VQA-Med", False),
-])
-def test_model(golden_dir, tag, tm, ds, supcon):
-    g = load(golden_dir, tag)
-    B, T, hw, V = [int(v) for v in g["dims"]]
+EFF = "tf_efficientnetv2_m"
+# (fixture, encoder, dataset, supcon head, backbone, --use_relu); the model_eff_* fixtures come from the reference's
+# own Timm_EFfNetV2 (image_encoding.py:89-115) at the shapes of BASELINE configs[2], [3], [4]
+MODEL_CASES = [
+    ("model_tr_roco", "transformer", "roco", False, "resnet152", False),
+    ("model_rf_roco_supcon", "realformer", "roco", True, "resnet152", False),
+    ("model_tr_vqa", "transformer", "VQA-Med", False, "resnet152", False),
+    ("model_rf_vqa", "realformer", "VQA-Med", False, "resnet152", False),
+    ("model_eff_rf_roco", "realformer", "roco", False, EFF, False),
+    ("model_eff_rf_roco_supcon", "realformer", "roco", True, EFF, False),
+    ("model_eff_rf_vqa_asl", "realformer", "VQA-Med", False, EFF, False),
+    ("model_eff_tr_roco_relu", "transformer", "roco", False, EFF, True),
+]
+
+
+def model_case_args(tm, ds, supcon, cnn, relu, V, **extra):
     kw = dict(transformer_model=tm, dataset=ds, hidden_size=768, n_layers=2, heads=12, hidden_dropout_prob=0.0,
-              vocab_size=V, resnet_layers=(1, 1, 1, 1), resnet_width=64, bert_max_pos=32)
+              vocab_size=V, resnet_layers=(1, 1, 1, 1), resnet_width=64, bert_max_pos=32, cnn_encoder=cnn,
+              use_relu=relu)
+    if "efficientnetv2" in cnn:
+        kw["effnet_depth_div"] = 8
     if supcon:
         kw["supcon"] = True
+    kw.update(extra)
+    return kw
+
+
+@pytest.mark.parametrize("tag,tm,ds,supcon,cnn,relu", MODEL_CASES)
+def test_model(golden_dir, tag, tm, ds, supcon, cnn, relu):
+    g = load(golden_dir, tag)
+    B, T, hw, V = [int(v) for v in g["dims"]]
+    kw = model_case_args(tm, ds, supcon, cnn, relu, V)
     args = O.make_args(**kw)
     torch.manual_seed(int(g["seed"]))
     m = O.OracleModel(args)
