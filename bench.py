@@ -41,6 +41,7 @@ def host_cores():
 
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32-input matrix peak
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 B_PER_GPU, T, HW, VOCAB = 16, 32, 224, 30522
 
 
@@ -59,7 +60,8 @@ def make_args():
 
 
 def cpu_baseline(seed):
-    """the oracle (CPU restatement, kind 'port') timed on this host: 10 steps of B=4 after 1 warm-up"""
+    """the oracle (CPU restatement, kind 'port') timed on this host at the SAME batch (16): median of 5 training
+    steps after 1 warm-up"""
     from oracle import mmbert_oracle as O
     from mmvqa_amd import synth
     torch.manual_seed(seed)
@@ -68,7 +70,7 @@ def cpu_baseline(seed):
     log(f"cpu_baseline: oracle on {cores} host threads")
     m = O.OracleModel(O.make_args(**vars(make_args()))).train()
     opt = torch.optim.Adam(m.parameters(), lr=2e-5)
-    Bc = 4
+    Bc = B_PER_GPU
     img, ids, seg, mask, tgt = synth.roco_batch(Bc, T, HW, VOCAB, seed=seed)
 
     def step():
@@ -79,14 +81,75 @@ def cpu_baseline(seed):
 
     step()
     log("cpu_baseline: warm-up step done")
-    t0 = time.perf_counter()
-    n = 10
+    times = []
+    n = 5
     for _ in range(n):
+        t0 = time.perf_counter()
         step()
-    dt = time.perf_counter() - t0
-    log(f"cpu_baseline: {n} steps in {dt:.1f}s")
-    return dict(value=Bc * n / dt, unit="samples/s", cores=cores, kind="port",
-                sample=f"{n} training steps of batch {Bc} (same model/shapes, fwd+loss+bwd+Adam) after 1 warm-up")
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[n // 2]
+    log(f"cpu_baseline: {n} steps, median {med:.2f}s")
+    return dict(value=Bc / med, unit="samples/s", cores=cores, kind="port", ms_per_step=med * 1e3,
+                sample=f"median of {n} training steps of batch {Bc} (same model, shapes and inputs as the GPU run: "
+                       f"fwd + log_softmax/NLL + bwd + Adam, dropout on, train-mode BN) after 1 warm-up")
+
+
+def per_block(regs, marks, model, a):
+    """SURVEY 8(d) per-block figures of ONE profiled step (HIP events per launch, both streams as in the timed steps):
+    MFMA-bound blocks as TFLOP/s and fraction of the fp32-MFMA peak, HBM-bound ones as GB/s and fraction of 8 TB/s."""
+    heads = 12 if CONFIG == 2 else 8
+    L = 4
+    M = B_PER_GPU * T
+
+    def gemm(*names):
+        ms = sum(regs[n]["igemm"]["ms"] for n in names)
+        fl = sum(regs[n]["igemm"]["flops"] for n in names)
+        nl = sum(regs[n]["igemm"]["launches"] for n in names)
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return dict(tflops=tf, frac_of_f32_mfma_peak=tf / PEAK_F32_MFMA_TFLOPS, ms=ms, launches=nl, gflop=fl / 1e9)
+
+    def region_ms(n):
+        return sum(v["ms"] for v in regs[n].values())
+
+    out = {}
+    out["qkv_gemm"] = gemm("qkv")                                  # fused QKV (or RealFormer kqv) fwd + dgrad + wgrad
+    at = regs["attention"]["attention"]
+    qk_ms = out["qkv_gemm"]["ms"] + at["ms"]
+    qk_fl = regs["qkv"]["igemm"]["flops"] + at["flops"]
+    tf = qk_fl / (qk_ms * 1e-3) / 1e12 if qk_ms > 0 else 0.0
+    out["qkv_plus_attention_block"] = dict(tflops=tf, frac_of_f32_mfma_peak=tf / PEAK_F32_MFMA_TFLOPS, ms=qk_ms,
+                                           gflop=qk_fl / 1e9, target_frac=0.60,
+                                           note="north-star block: QKV projection GEMMs + attention kernels, fwd+bwd, 4 layers")
+    # attention softmax: algorithmic bytes per SURVEY 8(d) = read scores + write probs = 2*B*h*T^2*4 per layer forward
+    # (x3 for forward + backward: probs re-read, dscores written and read); the tensors are L2-resident at T=32
+    sm_bytes = 2.0 * B_PER_GPU * heads * T * T * 4 * L * 3
+    out["attention_softmax"] = dict(ms=at["ms"], launches=at["launches"], algorithmic_mb=sm_bytes / 1e6,
+                                    gbps=sm_bytes / (at["ms"] * 1e-3) / 1e9 if at["ms"] > 0 else 0.0,
+                                    frac_of_hbm_peak=(sm_bytes / (at["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if at["ms"] > 0 else 0.0,
+                                    note="score/prob tiles live in registers and L2 (T=32): latency-bound, not HBM-bound")
+    out["backbone"] = dict(gemm("backbone", "tap"), total_ms_all_kernels=region_ms("backbone") + region_ms("tap") + region_ms("bn_coef"))
+    out["taps"] = gemm("tap")
+    out["encoder_rest"] = gemm("encoder_rest")
+    out["heads_K11"] = dict(gemm("heads"), total_ms_all_kernels=region_ms("heads"))
+    if "loss_fwd_a" in marks:
+        fwd_ms = marks["loss_fwd_a"].elapsed_time(marks["loss_fwd_b"])
+        lb = float(M) * VOCAB * 4
+        out["vocab_log_softmax_K12_fwd"] = dict(ms=fwd_ms, algorithmic_mb=lb / 1e6, gbps=lb / (fwd_ms * 1e-3) / 1e9,
+                                                frac_of_hbm_peak=lb / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                note="one read of the logits: row max/sum, NLL, argmax (+ the 512-row reduce)")
+        k11 = out["heads_K11"]
+        tot = k11["total_ms_all_kernels"] + fwd_ms
+        tf12 = k11["gflop"] * 1e9 / (tot * 1e-3) / 1e12 if tot > 0 else 0.0
+        out["heads_K11_plus_K12"] = dict(ms=tot, tflops=tf12, frac_of_f32_mfma_peak=tf12 / PEAK_F32_MFMA_TFLOPS,
+                                         note="head GEMMs fwd+bwd + LN + the loss forward pass (the dlogits pass runs inside backward)")
+        adam_ms = marks["adam_a"].elapsed_time(marks["adam_b"])
+        ab = 32.0 * model.flat_params.numel()   # read p,g,m,v + write p,m,v + zeroed g
+        out["adam"] = dict(ms=adam_ms, algorithmic_gb=ab / 1e9, gbps=ab / (adam_ms * 1e-3) / 1e9,
+                           frac_of_hbm_peak=ab / (adam_ms * 1e-3) / 1e9 / PEAK_HBM_GBS)
+    bc = regs["bn_coef"]["other"]
+    out["bn_coef"] = dict(launches=bc["launches"], ms=bc["ms"])
+    out["embed"] = dict(ms=region_ms("embed"))
+    return out
 
 
 def main():
@@ -133,12 +196,26 @@ def main():
         model.set_grad_ready_hook(red.start)   # all-reduce of finished gradient ranges overlaps the backbone backward
     img, ids, seg, mask, tgt = synth.roco_batch(B_PER_GPU, T, HW, VOCAB, seed=1234 + rank, device=dev)
 
-    def step():
+    marks = {}   # torch events around the launches that Python enqueues itself (loss kernels, Adam): same stream
+
+    def step(timed_parts=False):
+        ev = (lambda: torch.cuda.Event(enable_timing=True)) if timed_parts else None
+
+        def mark(name):
+            if timed_parts:
+                e = ev()
+                e.record()
+                marks[name] = e
+
         logits = model(img, ids, seg, mask)
+        mark("loss_fwd_a")
         loss, _, stats = mmvqa_amd.mlm_loss(logits, tgt)
+        mark("loss_fwd_b")
         loss.backward()
         red.allreduce()
+        mark("adam_a")
         opt.step(grad_scale=1.0 / world, zero_grad=True)
+        mark("adam_b")
         return stats
 
     def sync():
@@ -174,9 +251,10 @@ def main():
     roof = None
     if not a.no_roofline:
         model.profile(True)
-        step()
+        step(timed_parts=True)
         torch.cuda.synchronize()
         pr = model.profile_read()
+        regs = model.profile_read_regions()
         model.profile(False)
         g = pr["igemm"]
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
@@ -199,6 +277,7 @@ def main():
                                        avg_launch_us=gs["ms"] * 1e3 / max(1, gs["launches"]),
                                        note="same step with the second HIP stream disabled: no launch shares the chip"),
                     other_ms_per_step=dict(attention=pr["attention"]["ms"], elementwise=pr["other"]["ms"]))
+        roof["blocks"] = per_block(regs, marks, model, a)
 
     wl = ("pretrain/roco_train.py MLM-only: resnet152 + transformer(4 layers, 12 heads), " if CONFIG == 2 else
           "pretrain/roco_train.py MLM-only: tf_efficientnetv2_m + realformer(4 layers, 8 heads), ")

@@ -270,6 +270,12 @@ int mmvqa_engine_tune(mmvqa_engine* e, int enable);
  * a launch's time includes sharing the chip); enable = 2: everything on one stream; 0: off (both streams again) */
 int mmvqa_engine_profile(mmvqa_engine* e, int enable);
 int mmvqa_engine_profile_read(mmvqa_engine* e, int cls, long long* launches, double* ms, double* flops);
+/* the same split by region of the step (SURVEY 8(d) per-block figures): 0 CNN backbone, 1 tap 1x1 convs
+ * (image_encoding.py:53-62), 2 fused QKV / kqv projection (transformer.py:13-20, realformer.py:32-33) fwd+dgrad+wgrad,
+ * 3 attention core (transformer.py:22-27, realformer.py:34-44), 4 rest of the encoder, 5 heads (mmbert.py:133-137,
+ * 154-166), 6 embeddings, 7 BatchNorm coefficient kernels */
+int mmvqa_engine_profile_read_region(mmvqa_engine* e, int region, int cls, long long* launches, double* ms,
+                                     double* flops);
 
 #ifdef __cplusplus
 }

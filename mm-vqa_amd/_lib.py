@@ -116,6 +116,7 @@ SIGNATURES = {
     "mmvqa_engine_tune": (_i, [_P, _i]),
     "mmvqa_engine_profile": (_i, [_P, _i]),
     "mmvqa_engine_profile_read": (_i, [_P, _i, C.POINTER(_ll), C.POINTER(_d), C.POINTER(_d)]),
+    "mmvqa_engine_profile_read_region": (_i, [_P, _i, _i, C.POINTER(_ll), C.POINTER(_d), C.POINTER(_d)]),
 }
 
 _lib = None

@@ -234,7 +234,21 @@ int mmvqa_engine_profile(mmvqa_engine* e, int enable) {
     memset(e->prof_launch, 0, sizeof(e->prof_launch));
     memset(e->prof_ms, 0, sizeof(e->prof_ms));
     memset(e->prof_flops, 0, sizeof(e->prof_flops));
+    memset(e->reg_launch, 0, sizeof(e->reg_launch));
+    memset(e->reg_ms, 0, sizeof(e->reg_ms));
+    memset(e->reg_flops, 0, sizeof(e->reg_flops));
   }
+  return MMVQA_OK;
+}
+int mmvqa_engine_profile_read_region(mmvqa_engine* e, int region, int cls, long long* launches, double* ms,
+                                     double* flops) {
+  if (!e || cls < 0 || cls >= PROF_NCLS || region < 0 || region >= REG_N)
+    return mmvqa_set_error(MMVQA_ERR_ARG, "profile_read_region: bad region/class");
+  int r = engine_profile_collect(e);
+  if (r != MMVQA_OK) return r;
+  if (launches) *launches = e->reg_launch[region][cls];
+  if (ms) *ms = e->reg_ms[region][cls];
+  if (flops) *flops = e->reg_flops[region][cls];
   return MMVQA_OK;
 }
 int mmvqa_engine_profile_read(mmvqa_engine* e, int cls, long long* launches, double* ms, double* flops) {

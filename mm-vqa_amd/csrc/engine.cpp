@@ -436,7 +436,7 @@ static int prof_begin(mmvqa_engine* e, hipStream_t st, int cls, double flops) {
   mmvqa_engine::ProfRec r;
   HIP_CHECK_RET(hipEventCreate(&r.a));
   HIP_CHECK_RET(hipEventCreate(&r.b));
-  r.cls = cls; r.flops = flops;
+  r.cls = cls; r.reg = e->prof_reg; r.flops = flops;
   HIP_CHECK_RET(hipEventRecord(r.a, st));
   e->prof.push_back(r);
   return MMVQA_OK;
@@ -446,6 +446,12 @@ static int prof_end(mmvqa_engine* e, hipStream_t st) {
   HIP_CHECK_RET(hipEventRecord(e->prof.back().b, st));
   return MMVQA_OK;
 }
+struct RegScope {   // tags the launches of a scope with a profiler region
+  mmvqa_engine* e; int old;
+  RegScope(mmvqa_engine* e_, int r) : e(e_), old(e_->prof_reg) { e->prof_reg = r; }
+  ~RegScope() { e->prof_reg = old; }
+};
+#define REG(r) RegScope _reg_scope(e, r)
 #define RUN(cls, flops, call)          \
   do {                                 \
     TRY(prof_begin(e, st, cls, flops)); \
@@ -553,6 +559,7 @@ static void conv_geom(GemmParams& g, const ConvRef& c, int H, int W, int OH, int
 }
 
 static int bn_coef_fwd(mmvqa_engine* e, hipStream_t st, BNRef& bn) {
+  REG(REG_BNCOEF);
   RUN(PROF_OTHER, 0,
       k_bn_coef_fwd(st, stat_ptr(e, bn.stat_f), bn.C, bn.count, bn.eps, PRM(bn.gamma), PRM(bn.beta),
                     e->bufs + bn.rmean, e->bufs + bn.rvar, e->nbt + bn.nbt, 0.1f, bn.reps, e->training,
@@ -560,6 +567,7 @@ static int bn_coef_fwd(mmvqa_engine* e, hipStream_t st, BNRef& bn) {
   return MMVQA_OK;
 }
 static int bn_coef_bwd(mmvqa_engine* e, hipStream_t st, BNRef& bn) {
+  REG(REG_BNCOEF);
   RUN(PROF_OTHER, 0,
       k_bn_coef_bwd(st, stat_ptr(e, bn.stat_b), bn.C, bn.count, PRM(bn.gamma), WS(bn.mean), WS(bn.invstd),
                     e->training, WS(bn.P), WS(bn.Q), WS(bn.R), GRD(bn.gamma), GRD(bn.beta)));
@@ -635,6 +643,7 @@ static int conv_dgrad(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const f
 static int tap_act(const mmvqa_engine* e) { return e->d.use_relu ? ACT_RELU : ACT_SERF; }
 
 static int tap_fwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, const BNRef* bn_in) {
+  REG(REG_TAP);
   const TapRef& t = e->taps[k];
   GemmParams g = gp_linear_geom();
   g.M = (int)t.M; g.N = e->d.hidden; g.K = t.C;
@@ -651,6 +660,7 @@ static int tap_fwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, co
 // backward of one tap: du (recompute), dW_tap, and the gradient wrt the feature map (T_k or masked G)
 static int tap_bwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, const BNRef* bn_in, float* dfmap,
                    const EpiOpt& o) {
+  REG(REG_TAP);
   const TapRef& t = e->taps[k];
   const int Hd = e->d.hidden;
   GemmParams g = gp_linear_geom();
@@ -1128,6 +1138,7 @@ static inline uint32_t site_seed(const mmvqa_engine* e, int layer, int site) {
 }
 
 static int attn_call(mmvqa_engine* e, hipStream_t st, AttnParams& a, int head_dim, int bwd) {
+  REG(REG_ATTN);
   const double fl = (bwd ? 10.0 : 4.0) * (double)e->B * a.heads * e->T * e->T * head_dim;
   RUN(PROF_ATTN, fl, mmvqa_launch_attention(a, head_dim, bwd, st));
   return MMVQA_OK;
@@ -1135,6 +1146,7 @@ static int attn_call(mmvqa_engine* e, hipStream_t st, AttnParams& a, int head_di
 
 // models/transformer.py:75-86 (pre-LN, norm1 for both sub-layers, shared by all layers)
 static int bert_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, const float** x_out) {
+  REG(REG_ENC);
   const mmvqa_model_desc& d = e->d;
   const int H = d.hidden;
   const long M = (long)e->B * e->T;
@@ -1143,7 +1155,7 @@ static int bert_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, cons
   for (int i = 0; i < d.n_layers; ++i) {
     BertLayerRef& L = e->bert[i];
     TRY(ln_fwd(e, st, x, e->norm1, WS(L.xn1), WS(L.mean1), WS(L.rstd1), M, 1e-12f));
-    TRY(lin_fwd(e, st, WS(L.xn1), H, M, L.qkv, WS(L.qkvo), 3 * H, ACT_NONE, nullptr, 0.f, 0, nullptr, 0));
+    { REG(REG_QKV); TRY(lin_fwd(e, st, WS(L.xn1), H, M, L.qkv, WS(L.qkvo), 3 * H, ACT_NONE, nullptr, 0.f, 0, nullptr, 0)); }
     AttnParams a;
     memset(&a, 0, sizeof(a));
     a.q = WS(L.qkvo); a.k = a.q + H; a.v = a.q + 2 * H;
@@ -1165,6 +1177,7 @@ static int bert_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, cons
 
 // dz (in t_a) -> dx (left in t_a)
 static int bert_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
+  REG(REG_ENC);
   const mmvqa_model_desc& d = e->d;
   const int H = d.hidden;
   const long M = (long)e->B * e->T;
@@ -1206,8 +1219,9 @@ static int bert_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
     float* dqkv = WS(e->t_big);
     a.dq = dqkv; a.dk = dqkv + H; a.dv = dqkv + 2 * H;
     TRY(attn_call(e, st, a, H / d.heads, 1));
-    TRY(lin_wgrad(e, st, dqkv, 3 * H, WS(L.xn1), H, M, L.qkv, true));
-    TRY(lin_dgrad(e, st, dqkv, 3 * H, M, L.qkv, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0));  // dxn1
+    { REG(REG_QKV);
+      TRY(lin_wgrad(e, st, dqkv, 3 * H, WS(L.xn1), H, M, L.qkv, true));
+      TRY(lin_dgrad(e, st, dqkv, 3 * H, M, L.qkv, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0)); }  // dxn1
     TRY(ln_bwd(e, st, WS(e->t_c), x, e->norm1, WS(L.mean1), WS(L.rstd1), dy, dz, M));
   }
   return MMVQA_OK;
@@ -1215,6 +1229,7 @@ static int bert_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
 
 // models/realformer.py:30-51 (post-LN, shared per-head kqv, residual scores, query-axis mask)
 static int rf_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, const float** x_out) {
+  REG(REG_ENC);
   const mmvqa_model_desc& d = e->d;
   const int H = d.hidden, es = H / 8;
   const long M = (long)e->B * e->T;
@@ -1222,7 +1237,7 @@ static int rf_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, const 
   const float* x = x_in;
   for (int i = 0; i < d.n_layers; ++i) {
     RFLayerRef& L = e->rf[i];
-    TRY(lin_fwd(e, st, x, es, M * 8, L.kqv, WS(L.kqvo), 3 * es, ACT_NONE, nullptr, 0.f, 0, nullptr, 0));
+    { REG(REG_QKV); TRY(lin_fwd(e, st, x, es, M * 8, L.kqv, WS(L.kqvo), 3 * es, ACT_NONE, nullptr, 0.f, 0, nullptr, 0)); }
     AttnParams a;
     memset(&a, 0, sizeof(a));
     a.k = WS(L.kqvo); a.q = a.k + es; a.v = a.k + 2 * es;
@@ -1246,6 +1261,7 @@ static int rf_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, const 
 }
 
 static int rf_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
+  REG(REG_ENC);
   const mmvqa_model_desc& d = e->d;
   const int H = d.hidden, es = H / 8;
   const long M = (long)e->B * e->T;
@@ -1289,14 +1305,16 @@ static int rf_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
     a.dprev_in = (i < d.n_layers - 1) ? WS(e->t_dprev[(i + 1) & 1]) : nullptr;
     a.dprev_out = i > 0 ? WS(e->t_dprev[i & 1]) : nullptr;
     TRY(attn_call(e, st, a, es, 1));
-    TRY(lin_wgrad(e, st, dkqv, 3 * es, x, es, M * 8, L.kqv, false));
-    TRY(lin_dgrad(e, st, dkqv, 3 * es, M * 8, L.kqv, dx2, es, 0, nullptr, 0, nullptr, ds1, es));  // dx total
+    { REG(REG_QKV);
+      TRY(lin_wgrad(e, st, dkqv, 3 * es, x, es, M * 8, L.kqv, false));
+      TRY(lin_dgrad(e, st, dkqv, 3 * es, M * 8, L.kqv, dx2, es, 0, nullptr, 0, nullptr, ds1, es)); }  // dx total
   }
   return MMVQA_OK;
 }
 
 // --------------------------------------------------------------------------- heads (models/mmbert.py:150-167)
 static int heads_forward(mmvqa_engine* e, hipStream_t st, const float* h) {
+  REG(REG_HEAD);
   const mmvqa_model_desc& d = e->d;
   const int H = d.hidden;
   const long M = (long)e->B * e->T;
@@ -1327,6 +1345,7 @@ static int heads_forward(mmvqa_engine* e, hipStream_t st, const float* h) {
 // produces dh (gradient wrt the encoder output) in t_a
 static int heads_backward(mmvqa_engine* e, hipStream_t st, const float* h, const float* dlogits, int dl_ld,
                           const float* dfeat) {
+  REG(REG_HEAD);
   const mmvqa_model_desc& d = e->d;
   const int H = d.hidden;
   const long M = (long)e->B * e->T;
@@ -1379,10 +1398,12 @@ int engine_forward(mmvqa_engine* e, hipStream_t st, const float* img, const long
   e->ev_next = 0;
   if (d.cnn == 1) TRY(effnet_forward(e, st)); else TRY(resnet_forward(e, st));
   const float pe = training ? d.p_emb_drop : 0.f;
+  e->prof_reg = REG_EMBED;
   RUN(PROF_OTHER, 0,
       k_embed_fwd(st, ids, seg, PRM(e->emb_word), PRM(e->emb_pos), PRM(e->emb_type), PRM(e->emb_ln.g),
                   PRM(e->emb_ln.b), WS(e->vis), WS(e->emb_out), WS(e->emb_xhat), WS(e->emb_rstd), e->B, e->T,
                   d.hidden, d.num_vis, 1e-12f, pe, site_seed(e, 100, 0)));
+  e->prof_reg = REG_BACKBONE;
   const float* h = nullptr;
   if (d.encoder == 0) TRY(bert_forward(e, st, WS(e->emb_out), &h));
   else TRY(rf_forward(e, st, WS(e->emb_out), &h));
@@ -1401,10 +1422,12 @@ int engine_backward(mmvqa_engine* e, hipStream_t st, const float* dlogits, int d
   else TRY(rf_backward(e, st, WS(e->emb_out)));
   if (e->grad_cb) e->grad_cb(e->grad_cb_user, e->enc_lo, e->n_params);   // heads + encoder gradients are final
   const float pe = e->training ? d.p_emb_drop : 0.f;
+  e->prof_reg = REG_EMBED;
   RUN(PROF_OTHER, 0,
       k_embed_bwd(st, WS(e->t_a), e->ids, e->seg, WS(e->emb_xhat), WS(e->emb_rstd), PRM(e->emb_ln.g),
                   GRD(e->emb_word), GRD(e->emb_pos), GRD(e->emb_type), GRD(e->emb_ln.g), GRD(e->emb_ln.b),
                   WS(e->dvis), e->B, e->T, d.hidden, d.num_vis, pe, site_seed(e, 100, 0), 0));
+  e->prof_reg = REG_BACKBONE;
   if (e->grad_cb) e->grad_cb(e->grad_cb_user, 0, e->emb_hi);            // embedding tables + LayerNorm
   return d.cnn == 1 ? effnet_backward(e, st) : resnet_backward(e, st);
 }
@@ -1424,6 +1447,9 @@ int engine_create(const mmvqa_model_desc* desc, mmvqa_engine** out) {
   memset(e->prof_launch, 0, sizeof(e->prof_launch));
   memset(e->prof_ms, 0, sizeof(e->prof_ms));
   memset(e->prof_flops, 0, sizeof(e->prof_flops));
+  memset(e->reg_launch, 0, sizeof(e->reg_launch));
+  memset(e->reg_ms, 0, sizeof(e->reg_ms));
+  memset(e->reg_flops, 0, sizeof(e->reg_flops));
   int r = build_tables(e);
   if (r != MMVQA_OK) { delete e; return r; }
   *out = e;
@@ -1438,6 +1464,9 @@ int engine_profile_collect(mmvqa_engine* e) {
     e->prof_launch[r.cls] += 1;
     e->prof_ms[r.cls] += ms;
     e->prof_flops[r.cls] += r.flops;
+    e->reg_launch[r.reg][r.cls] += 1;
+    e->reg_ms[r.reg][r.cls] += ms;
+    e->reg_flops[r.reg][r.cls] += r.flops;
     hipEventDestroy(r.a);
     hipEventDestroy(r.b);
   }

@@ -84,6 +84,9 @@ struct RFLayerRef {
 };
 
 enum { PROF_IGEMM = 0, PROF_ATTN = 1, PROF_OTHER = 2, PROF_NCLS = 3 };
+// profiler regions (per-block rooflines): which part of the step a launch belongs to
+enum { REG_BACKBONE = 0, REG_TAP = 1, REG_QKV = 2, REG_ATTN = 3, REG_ENC = 4, REG_HEAD = 5, REG_EMBED = 6,
+       REG_BNCOEF = 7, REG_N = 8 };
 
 struct mmvqa_engine {
   mmvqa_model_desc d;
@@ -146,8 +149,11 @@ struct mmvqa_engine {
   long long enc_lo = 0, emb_hi = 0;
   // ---- profiling
   int prof_on = 0;
-  struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+  int prof_reg = REG_BACKBONE;
+  struct ProfRec { hipEvent_t a, b; int cls, reg; double flops; };
   std::vector<ProfRec> prof;
   long long prof_launch[PROF_NCLS];
   double prof_ms[PROF_NCLS], prof_flops[PROF_NCLS];
+  long long reg_launch[REG_N][PROF_NCLS];
+  double reg_ms[REG_N][PROF_NCLS], reg_flops[REG_N][PROF_NCLS];
 };

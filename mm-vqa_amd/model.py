@@ -411,6 +411,20 @@ class Model(nn.Module):
         """per-launch HIP-event timing of the next step; serialized=True puts every launch on one stream"""
         L.check(L.lib().mmvqa_engine_profile(self._handle, (2 if serialized else 1) if enable else 0))
 
+    REGIONS = ("backbone", "tap", "qkv", "attention", "encoder_rest", "heads", "embed", "bn_coef")
+
+    def profile_read_regions(self):
+        """{region: {class: {launches, ms, flops}}} of the profiled step (mmvqa_engine_profile_read_region)"""
+        out = {}
+        for r, rn in enumerate(self.REGIONS):
+            out[rn] = {}
+            for cls, nm in enumerate(("igemm", "attention", "other")):
+                n, ms, fl = C.c_longlong(), C.c_double(), C.c_double()
+                L.check(L.lib().mmvqa_engine_profile_read_region(self._handle, r, cls, C.byref(n), C.byref(ms),
+                                                                 C.byref(fl)))
+                out[rn][nm] = dict(launches=n.value, ms=ms.value, flops=fl.value)
+        return out
+
     def profile_read(self):
         out = {}
         for cls, nm in enumerate(("igemm", "attention", "other")):

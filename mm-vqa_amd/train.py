@@ -135,6 +135,60 @@ def maybe_resume(args, model, opt, sched):
     return rec["epoch"] + 1
 
 
+# ----------------------------------------------------------------------------------------- one training step each
+def mlm_step(model, opt, red, world, batch):
+    """pretrain/roco_utils.py:214-247,257-265: zero_grad -> forward -> log_softmax + NLLLoss -> backward ->
+    (gradient all-reduce) -> Adam.  Returns (loss, pred[B,T], stats = {loss, #target>0, #correct})."""
+    img, ids, seg, mask, tgt = batch
+    opt.zero_grad()
+    loss, pred, stats = mlm_loss(model(img, ids, seg, mask), tgt)
+    loss.backward()
+    red.allreduce()
+    opt.step(grad_scale=1.0 / world, zero_grad=True)
+    return loss, pred, stats
+
+
+def process_tensors(img, caption_token, aug_tokens, segment_ids, attention_mask, target, aug_targets):
+    """models/SupConLoss/supcon_utils.py:253-256: the two views concatenated along the batch; segment ids and
+    attention mask of view 1 are used for BOTH views"""
+    cat = lambda a, b: torch.cat([a, b], dim=0)   # noqa: E731
+    return (cat(img[0], img[1]), cat(caption_token, aug_tokens), cat(segment_ids, segment_ids),
+            cat(attention_mask, attention_mask), cat(target, aug_targets))
+
+
+def supcon_step(model, opt, red, world, batch):
+    """models/SupConLoss/supcon_utils.py:270-294: MLM loss over both views + SupCon(split_feat(feat)) (called without
+    a mask => SimCLR, :287); under DDP the views of all ranks are gathered first.  Returns (loss, pred, stats)."""
+    img, ids, seg, mask, tgt = batch
+    opt.zero_grad()
+    logits, feat = model(img, ids, seg, mask)
+    loss_mlm, pred, stats = mlm_loss(logits, tgt)
+    bsz = img.shape[0] // 2                        # supcon_utils.py:284 (2 = n_views)
+    feat = global_supcon_views(feat, bsz)          # = split_feat(feat, bsz) on one rank; global negatives under DDP
+    loss = loss_mlm + supcon_loss(feat)            # 2N*world rows: the tiled kernel has no size cap
+    loss.backward()
+    red.allreduce()
+    opt.step(grad_scale=1.0 / world, zero_grad=True)
+    return loss, pred, stats
+
+
+def vqa_step(model, opt, red, world, batch, crit, clip=False):
+    """vqamed2019/utils.py:633-673: logits, _, _ = model(...); loss = criterion(logits, target); backward;
+    optional clip_grad_norm_(1.0) (:663-664); Adam; pred = softmax(1).argmax(1)"""
+    img, ids, seg, mask, tgt = batch
+    opt.zero_grad()
+    logits, _, _ = model(img, ids, seg, mask)       # utils.py:646
+    loss = crit(logits, tgt)
+    loss.backward()
+    red.allreduce()
+    scale = 1.0 / world
+    if clip:                                        # global 2-norm over the (averaged) flat gradient buffer
+        gn = float(model.flat_grads.norm()) * scale
+        scale *= min(1.0, 1.0 / (gn + 1e-6))
+    opt.step(grad_scale=scale, zero_grad=True)
+    return loss, logits.detach().softmax(1).argmax(1)
+
+
 # ----------------------------------------------------------------------------------------- MLM
 def run_mlm(args):
     ctx = Ctx(args)
@@ -149,11 +203,7 @@ def run_mlm(args):
             img, ids, seg, mask, tgt = synth.roco_batch(B, T, args.image_size, min(V, args.emb_vocab),
                                                         seed=args.seed + 7919 * (epoch * 100003 + i) + ctx.rank,
                                                         device=ctx.dev, mlm_prob=args.mlm_prob)
-            opt.zero_grad()
-            loss, pred, stats = mlm_loss(model(img, ids, seg, mask), tgt)
-            loss.backward()
-            red.allreduce()
-            opt.step(grad_scale=1.0 / ctx.world, zero_grad=True)
+            _, _, stats = mlm_step(model, opt, red, ctx.world, (img, ids, seg, mask, tgt))
             s = stats.tolist()               # per-step host sync, as roco_utils.py:267
             tl, nm, nc = tl + s[0], nm + s[1], nc + s[2]
         vl, va = validate_mlm(args, ctx, model, epoch)
@@ -203,17 +253,8 @@ def run_supcon(args):
             sd = args.seed + 7919 * (epoch * 100003 + i) + ctx.rank
             a = synth.roco_batch(n, T, args.image_size, min(V, args.emb_vocab), seed=sd, device=ctx.dev, mlm_prob=args.mlm_prob)
             b = synth.roco_batch(n, T, args.image_size, min(V, args.emb_vocab), seed=sd + 1, device=ctx.dev, mlm_prob=args.mlm_prob)
-            # process_tensors (supcon_utils.py:253-256): views concatenated along the batch; segment ids / mask of view 1
-            img, ids, tgt = (torch.cat([x, y], 0) for x, y in ((a[0], b[0]), (a[1], b[1]), (a[4], b[4])))
-            seg, mask = torch.cat([a[2], a[2]], 0), torch.cat([a[3], a[3]], 0)
-            opt.zero_grad()
-            logits, feat = model(img, ids, seg, mask)
-            loss = mlm_loss(logits, tgt)[0]
-            feat = global_supcon_views(feat, n)    # split_feat over the all-gathered views (global negatives)
-            loss = loss + supcon_loss(feat)         # 2N*world rows: the tiled kernel has no size cap
-            loss.backward()
-            red.allreduce()
-            opt.step(grad_scale=1.0 / ctx.world, zero_grad=True)
+            batch = process_tensors((a[0], b[0]), a[1], b[1], a[2], a[3], a[4], b[4])
+            loss, _, _ = supcon_step(model, opt, red, ctx.world, batch)
             tl += float(loss.detach())
         vl, va = validate_mlm(args, ctx, model, epoch)
         sched.step(vl)
@@ -245,12 +286,7 @@ def run_vqa(args):
         for i in range(args.steps_per_epoch):
             img, ids, seg, mask, tgt = synth.vqa_batch(B, T, args.image_size, args.emb_vocab, C,
                                                        seed=args.seed + 7919 * (epoch * 100003 + i) + ctx.rank, device=ctx.dev)
-            opt.zero_grad()
-            logits, _, _ = model(img, ids, seg, mask)       # utils.py:646
-            loss = crit(logits, tgt)
-            loss.backward()
-            red.allreduce()
-            opt.step(grad_scale=1.0 / ctx.world, zero_grad=True)
+            loss, _ = vqa_step(model, opt, red, ctx.world, (img, ids, seg, mask, tgt), crit, clip=args.clip)
             tl += float(loss.detach())
         model.eval()
         vl, correct, total = 0.0, 0, 0
@@ -304,6 +340,7 @@ def main(argv=None):
         p.add_argument("--loss", type=str, default="CrossEntropyLoss", choices=["CrossEntropyLoss", "ASLSingleLabel"])
         p.add_argument("--num_classes", type=int, default=1552)
         p.add_argument("--counter", type=int, default=20)
+        p.add_argument("--clip", action="store_true", default=False, help="clip_grad_norm_(1.0), utils.py:663-664")
     args = p.parse_args(argv)
     out = {"mlm": run_mlm, "supcon": run_supcon, "vqa": run_vqa}[mode](args)
     if dist.is_initialized():

@@ -350,6 +350,8 @@ def test_stock_torch_adam_steps_the_flat_buffer():
     assert len(used) > 30 and not any(n.startswith("transformer.blocks.norm2") for n in used)
     pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
     for n in pa:   # (elements whose gradient is ~0 are decided by the order of the float atomics: allow 1 %)
+        if n.endswith("proj_k.bias"):   # gradient identically 0 in exact arithmetic (softmax shift invariance): pure noise
+            continue
         off = ((pa[n].detach() - pb[n].detach()).abs() > 0.05 * lr).float().mean().item()
         assert off <= 0.01, f"{n}: {off:.3f} of the elements differ between FusedAdam and torch.optim.Adam after two steps"
 

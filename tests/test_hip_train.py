@@ -61,8 +61,8 @@ def test_resume_keeps_scheduler_wired(tmp_path):
     assert start == 5 and opt.step_count == 30
     assert opt.param_groups[0]["lr"] == pytest.approx(1e-3)     # the checkpoint's lr, not the constructor's
     assert float(opt.m.abs().sum()) > 0
-    sched.step(1.0)
-    sched.step(2.0)                                             # no improvement with patience 0 -> reduce
+    for _ in range(sched.patience + 1):                         # (patience/best come from the checkpoint)
+        sched.step(1e9)                                         # no improvement for patience+1 epochs -> reduce
     assert opt.param_groups[0]["lr"] == pytest.approx(1e-4)     # ... and the fused optimizer sees it
     p0 = model.flat_params.clone()
     model.flat_grads.fill_(1.0)

@@ -185,3 +185,23 @@ def test_model(golden_dir, tag, tm, ds, supcon, cnn, relu):
     for k in g:
         if k.startswith("b_"):
             close(bsd[k[2:].replace("__", ".")].double(), g[k], 1e-5, k)
+
+
+def test_loop_restatement_first_step_equals_reference_loss(golden_dir):
+    """oracle/loops_oracle.py (a20: the step loops) on the inputs of the reference-generated model fixtures: the loss
+    of the first step equals the REFERENCE's loss; the second step on the same batch is lower (the optimizer moved)"""
+    from oracle import loops_oracle as LO
+    for tag, tm, ds, supcon, cnn, relu in (MODEL_CASES[0], MODEL_CASES[3]):
+        g = load(golden_dir, tag)
+        B, T, hw, V = [int(v) for v in g["dims"]]
+        torch.manual_seed(int(g["seed"]))
+        m = O.OracleModel(O.make_args(**model_case_args(tm, ds, supcon, cnn, relu, V)))
+        zero_dropout(m)
+        batch = (t(g["img"]), t(g["ids"]), t(g["seg"]), t(g["mask"]), t(g["target"]))
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        if ds == "roco":
+            _, _, losses, _ = LO.mlm_train_one_epoch([batch, batch], m, torch.nn.NLLLoss(), opt)
+        else:
+            _, _, losses, _ = LO.vqa_train_one_epoch([batch, batch], m, opt, O.asl_single_label)
+        close(losses[0], g["loss"], 2e-5, tag + " first-step loss")
+        assert float(losses[1]) < float(losses[0])
