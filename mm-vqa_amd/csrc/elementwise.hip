@@ -11,22 +11,33 @@ static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
 // torchvision BatchNorm2d as the reference drives it (models/image_encoding.py:72-86):
 // train mode -> batch statistics (biased var) + running-stat update repeated `reps` times
 // with the same statistics; eval mode -> running statistics.
-__global__ void bn_coef_fwd_kernel(const double* __restrict__ stat, int C, double count, float eps,
+// One 16-lane group per channel: lane k reads replica k of the (sum, sum of squares) pair with one 16-byte load
+// and the group folds them with four shuffles (a thread per channel walking the 16 replicas serially made the
+// kernel 4.8 us of pure load latency, 310 times per step on the critical path between two convolutions).
+static_assert(MMVQA_STAT_SLOTS == 16, "one lane per statistics replica");
+__device__ __forceinline__ void stat_fold16(const double* __restrict__ stat, int C, int c, bool live, double& s0,
+                                            double& s1) {
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  const int sl = threadIdx.x & 15;
+  f64x2 v = {0.0, 0.0};
+  if (live) v = *reinterpret_cast<const f64x2*>(stat + ((size_t)sl * C + c) * 2);
+  s0 = v[0]; s1 = v[1];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+}
+__global__ __launch_bounds__(256) void bn_coef_fwd_kernel(const double* __restrict__ stat, int C, double count, float eps,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ run_mean, float* __restrict__ run_var,
                                    long long* __restrict__ nbt, double keep, int reps, int training,
                                    float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && training && nbt) *nbt += reps;
-  if (c >= C) return;
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && training && nbt) *nbt += reps;
+  double s = 0.0, ss = 0.0;
+  if (training) stat_fold16(stat, C, c, c < C, s, ss);
+  if (c >= C || (threadIdx.x & 15) != 0) return;
   float mean, invstd;
   if (training) {
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < MMVQA_STAT_SLOTS; ++k) {
-      s += stat[((size_t)k * C + c) * 2];
-      ss += stat[((size_t)k * C + c) * 2 + 1];
-    }
     double mu = s / count;
     double var = ss / count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -49,18 +60,15 @@ __global__ void bn_coef_fwd_kernel(const double* __restrict__ stat, int C, doubl
 }
 
 // dz = P*g + Q*z + R  with g = dL/d(bn output); also dgamma += sum g*xhat, dbeta += sum g
-__global__ void bn_coef_bwd_kernel(const double* __restrict__ stat, int C, double count,
+__global__ __launch_bounds__(256) void bn_coef_bwd_kernel(const double* __restrict__ stat, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ mean,
                                    const float* __restrict__ invstd, int training,
                                    float* __restrict__ P, float* __restrict__ Q, float* __restrict__ R,
                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double sg = 0.0, sgx = 0.0;
-  for (int k = 0; k < MMVQA_STAT_SLOTS; ++k) {
-    sg += stat[((size_t)k * C + c) * 2];
-    sgx += stat[((size_t)k * C + c) * 2 + 1];
-  }
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+  double sg, sgx;
+  stat_fold16(stat, C, c, c < C, sg, sgx);
+  if (c >= C || (threadIdx.x & 15) != 0) return;
   double p = (double)gamma[c] * (double)invstd[c];
   if (training) {
     double c1 = sg / count, c2 = sgx / count;
@@ -587,7 +595,7 @@ __global__ void __launch_bounds__(1024) lsm_stats_kernel(const float* __restrict
 #pragma unroll
       for (int u = 0; u < LSM_U; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc += expf(v[u][e] - cm);   // exp(-inf) = 0 for masked slots
+        for (int e = 0; e < 4; ++e) acc += __expf(v[u][e] - cm);   // hardware exp2 path (rel. error ~1e-6, averaged over V terms); exp(-inf) = 0 for masked slots
       s = (m == -INFINITY ? 0.f : s * expf(m - cm)) + acc;
       m = cm;
     }
@@ -637,7 +645,7 @@ __global__ void __launch_bounds__(256) lsm_grad_kernel(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i = j * 4 + e;
-      o[e] = i < V ? (expf(v[u][e] - lse) - (i == tg ? 1.f : 0.f)) * gs : 0.f;
+      o[e] = i < V ? (__expf(v[u][e] - lse) - (i == tg ? 1.f : 0.f)) * gs : 0.f;
     }
     d4[j] = o;
   }
@@ -972,7 +980,7 @@ static inline int grid_for(long n, int block = 256, int cap = 2048) {
 int k_bn_coef_fwd(hipStream_t st, const double* stat, int C, double count, float eps, const float* gamma,
                   const float* beta, float* run_mean, float* run_var, long long* nbt, float momentum, int reps,
                   int training, float* scale, float* shift, float* mean, float* invstd) {
-  hipLaunchKernelGGL(bn_coef_fwd_kernel, dim3(cdiv_i(C, 256)), dim3(256), 0, st, stat, C, count, eps, gamma, beta,
+  hipLaunchKernelGGL(bn_coef_fwd_kernel, dim3(cdiv_i(C, 16)), dim3(256), 0, st, stat, C, count, eps, gamma, beta,
                      run_mean, run_var, nbt, pow(1.0 - (double)momentum, (double)reps), reps, training, scale, shift,
                      mean, invstd);   // (1 - momentum)^reps on the host: a double pow() per thread was most of the kernel's math
   KERNEL_CHECK_RET();
@@ -981,7 +989,7 @@ int k_bn_coef_fwd(hipStream_t st, const double* stat, int C, double count, float
 
 int k_bn_coef_bwd(hipStream_t st, const double* stat, int C, double count, const float* gamma, const float* mean,
                   const float* invstd, int training, float* P, float* Q, float* R, float* dgamma, float* dbeta) {
-  hipLaunchKernelGGL(bn_coef_bwd_kernel, dim3(cdiv_i(C, 256)), dim3(256), 0, st, stat, C, count, gamma, mean,
+  hipLaunchKernelGGL(bn_coef_bwd_kernel, dim3(cdiv_i(C, 16)), dim3(256), 0, st, stat, C, count, gamma, mean,
                      invstd, training, P, Q, R, dgamma, dbeta);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
@@ -1410,34 +1418,59 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
 }
 
 // squeeze: pool[n][c] = mean_hw silu(z*s+b)
-__global__ void se_pool_kernel(const float* __restrict__ z, const float* __restrict__ s, const float* __restrict__ b,
-                               float* __restrict__ pool, int HW, int C) {
-  const int n = blockIdx.y, c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (c >= C) return;
-  f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c), acc = {0, 0, 0, 0};
-  for (int p = 0; p < HW; ++p) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(z + ((size_t)n * HW + p) * C + c);
+// Workgroup = 16 channel quads (64 channels) x 16 pixel lanes of ONE image: every pixel row of the chunk is a
+// 256-byte segment, the HW pixels are spread over the 16 lanes and reduced through LDS (one thread per image and
+// channel quad walking all HW pixels serially left the chip at 80 waves and 46 us per call: round-2 profile).
+__global__ __launch_bounds__(256) void se_pool_kernel(const float* __restrict__ z, const float* __restrict__ s,
+                                                      const float* __restrict__ b, float* __restrict__ pool, int HW,
+                                                      int C) {
+  __shared__ f32x4 red[16][17];
+  const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int n = blockIdx.y, c = blockIdx.x * 64 + q * 4;
+  f32x4 acc = {0, 0, 0, 0};
+  if (c < C) {
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c);
+    for (int p = pl; p < HW; p += 16) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(z + ((size_t)n * HW + p) * C + c);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] += silu_f(v[j] * sv[j] + bv[j]);
+      for (int j = 0; j < 4; ++j) acc[j] += silu_f(v[j] * sv[j] + bv[j]);
+    }
   }
+  red[pl][q] = acc;
+  __syncthreads();
+  if (pl == 0 && c < C) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] /= (float)HW;
-  *reinterpret_cast<f32x4*>(pool + (size_t)n * C + c) = acc;
+    for (int r = 1; r < 16; ++r) acc += red[r][q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] /= (float)HW;
+    *reinterpret_cast<f32x4*>(pool + (size_t)n * C + c) = acc;
+  }
 }
 
-// dgate[n][c] = sum_hw t[pix,c] * silu(z*s+b)[pix,c]   (t = gradient wrt the gated activation)
-__global__ void se_dgate_kernel(const float* __restrict__ t, const float* __restrict__ z, const float* __restrict__ s,
-                                const float* __restrict__ b, float* __restrict__ dgate, int HW, int C) {
-  const int n = blockIdx.y, c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (c >= C) return;
-  f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c), acc = {0, 0, 0, 0};
-  for (int p = 0; p < HW; ++p) {
-    size_t o = ((size_t)n * HW + p) * C + c;
-    f32x4 v = *reinterpret_cast<const f32x4*>(z + o), tv = *reinterpret_cast<const f32x4*>(t + o);
+// dgate[n][c] = sum_hw t[pix,c] * silu(z*s+b)[pix,c]   (t = gradient wrt the gated activation); same shape
+__global__ __launch_bounds__(256) void se_dgate_kernel(const float* __restrict__ t, const float* __restrict__ z,
+                                                       const float* __restrict__ s, const float* __restrict__ b,
+                                                       float* __restrict__ dgate, int HW, int C) {
+  __shared__ f32x4 red[16][17];
+  const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int n = blockIdx.y, c = blockIdx.x * 64 + q * 4;
+  f32x4 acc = {0, 0, 0, 0};
+  if (c < C) {
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c);
+    for (int p = pl; p < HW; p += 16) {
+      const size_t o = ((size_t)n * HW + p) * C + c;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(z + o), tv = *reinterpret_cast<const f32x4*>(t + o);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] += tv[j] * silu_f(v[j] * sv[j] + bv[j]);
+      for (int j = 0; j < 4; ++j) acc[j] += tv[j] * silu_f(v[j] * sv[j] + bv[j]);
+    }
   }
-  *reinterpret_cast<f32x4*>(dgate + (size_t)n * C + c) = acc;
+  red[pl][q] = acc;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+#pragma unroll
+    for (int r = 1; r < 16; ++r) acc += red[r][q];
+    *reinterpret_cast<f32x4*>(dgate + (size_t)n * C + c) = acc;
+  }
 }
 
 // du = (t * gate[n][c] + add[n][c] / HW) * act'(z*s+b) -> out ; BatchNorm-backward sums of bn(z)
@@ -1549,14 +1582,14 @@ int k_dwconv_bwd_weight(hipStream_t st, const float* g2, const float* z2, const 
 }
 
 int k_se_pool(hipStream_t st, const float* z, const float* s, const float* b, float* pool, int N, int HW, int C) {
-  hipLaunchKernelGGL(se_pool_kernel, dim3(cdiv_i(C / 4, 64), N), dim3(64), 0, st, z, s, b, pool, HW, C);
+  hipLaunchKernelGGL(se_pool_kernel, dim3(cdiv_i(C, 64), N), dim3(256), 0, st, z, s, b, pool, HW, C);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }
 
 int k_se_dgate(hipStream_t st, const float* t, const float* z, const float* s, const float* b, float* dgate, int N,
                int HW, int C) {
-  hipLaunchKernelGGL(se_dgate_kernel, dim3(cdiv_i(C / 4, 64), N), dim3(64), 0, st, t, z, s, b, dgate, HW, C);
+  hipLaunchKernelGGL(se_dgate_kernel, dim3(cdiv_i(C, 64), N), dim3(256), 0, st, t, z, s, b, dgate, HW, C);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }

@@ -60,14 +60,23 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Phase timestamps of every workgroup (tools/igemm_trace.py builds the library with -DIGEMM_TRACE):
 // [wg][8] = {entry, loader state ready, first tile in LDS, K loop done, end} in s_memtime ticks (per-XCD counter),
 // HW_ID | XCC_ID << 32, entry and end in s_memrealtime ticks (100 MHz, chip-wide).
+#if !defined(IGEMM_TRACE) && (defined(EXP_SAMETILE) || defined(EXP_NOADVANCE) || defined(EXP_NOBAR) || \
+                             defined(EXP_NOLOAD) || defined(EXP_NOSTORE) || defined(EXP_NOSTOREC))
+#error "the EXP_* ablation switches produce wrong results by design: tracer builds (-DIGEMM_TRACE, tools/igemm_trace.py) only"
+#endif
 #ifdef IGEMM_TRACE
 __device__ unsigned long long* g_igemm_trace = nullptr;
 extern "C" int mmvqa_debug_set_trace(unsigned long long* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
 }
+// capacity of the two record regions of the trace buffer (8 words per workgroup each): tools/igemm_trace.py
+// allocates (1 << 22) + (1 << 20) words; a workgroup beyond a region's capacity records nothing
+#define TRACE_WG ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)
+#define TRACE_CAP0 ((size_t)(1 << 22) / 8)
+#define TRACE_CAP1 ((size_t)(1 << 20) / 8)
 #define TRACE_MARK(i)                                                                              \
   do {                                                                                             \
-    if (g_igemm_trace && threadIdx.x == 0) {                                                       \
+    if (g_igemm_trace && threadIdx.x == 0 && TRACE_WG < TRACE_CAP0) {                              \
       unsigned long long* t_ = g_igemm_trace + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; \
       t_[i] = __builtin_readcyclecounter();                                                        \
       if ((i) == 0) {                                                                              \
@@ -81,14 +90,14 @@ extern "C" int mmvqa_debug_set_trace(unsigned long long* buf) {
 #define TRACE_STALL_DECL unsigned long long tr_vm = 0, tr_lgkm = 0, tr_bar = 0;
 #define TRACE_STALL_FLUSH()                                                                        \
   do {                                                                                             \
-    if (g_igemm_trace && threadIdx.x == 0) {                                                       \
+    if (g_igemm_trace && threadIdx.x == 0 && TRACE_WG < TRACE_CAP1) {                              \
       unsigned long long* t_ = g_igemm_trace + (1 << 22) + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; \
       t_[0] = tr_vm; t_[1] = tr_lgkm; t_[2] = tr_bar;                                              \
     }                                                                                              \
   } while (0)
 #define TRACE_EPI(i)                                                                               \
   do {                                                                                             \
-    if (g_igemm_trace && threadIdx.x == 0)                                                         \
+    if (g_igemm_trace && threadIdx.x == 0 && TRACE_WG < TRACE_CAP1)                                \
       g_igemm_trace[(1 << 22) + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + 4 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
 #else
@@ -1331,8 +1340,51 @@ static std::string tune_key(const GemmParams& p, int kind, int nchw) {
 
 static int launch_one(GemmParams p, int kind, int nchw, int tile, hipStream_t stream);
 
+// Host-side consistency check of a descriptor.  The loaders address the operands from (M, N, K, geometry, leading
+// dimensions) alone -- the uniform-tap path even lets the hardware range check of a 2 GB buffer window stand in for
+// per-element bounds tests -- so a descriptor whose dimensions disagree with each other (or a prologue / epilogue
+// option without its tensors) would read outside the caller's buffers.  Such a descriptor is refused here.
+static int validate_desc(const GemmParams& p, int kind, int nchw) {
+#define BAD(...) return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: " __VA_ARGS__)
+  if (kind < KIND_FWD || kind > KIND_WGRAD) BAD("unknown kind %d", kind);
+  if (!p.A || !p.B) BAD("operand pointer is null (A=%p B=%p)", (const void*)p.A, (const void*)p.B);
+  if (!p.C && p.epi_mode != EPI_TAP_FWD) BAD("output pointer is null");
+  const int KH = p.g_KH > 0 ? p.g_KH : 1, KW = p.g_KH > 0 ? p.g_KW : 1;
+  const long taps = (long)KH * KW;
+  if (KW <= 0 || p.g_Cs <= 0 || (p.g_KH > 0 && (p.g_stride <= 0 || p.g_pad < 0))) BAD("bad geometry (KH=%d KW=%d Cs=%d stride=%d pad=%d)", p.g_KH, p.g_KW, p.g_Cs, p.g_stride, p.g_pad);
+  if (p.g_OH <= 0 || p.g_OW <= 0 || p.g_SH <= 0 || p.g_SW <= 0) BAD("bad image dims (SH=%d SW=%d OH=%d OW=%d)", p.g_SH, p.g_SW, p.g_OH, p.g_OW);
+  const long ohw = (long)p.g_OH * p.g_OW;
+  if (kind == KIND_WGRAD) {
+    if ((long)p.N != taps * p.g_Cs) BAD("wgrad: N=%d != taps*Cs=%ld", p.N, taps * p.g_Cs);
+    if (p.K % ohw) BAD("wgrad: K=%d is not a multiple of OH*OW=%ld", p.K, ohw);
+    if (p.a_ld < p.M || (!nchw && p.b_ld < p.g_Cs) || p.c_ld < p.N) BAD("wgrad: leading dimension too small (a_ld=%d M=%d b_ld=%d Cs=%d c_ld=%d N=%d)", p.a_ld, p.M, p.b_ld, p.g_Cs, p.c_ld, p.N);
+  } else {
+    if ((long)p.K != taps * p.g_Cs) BAD("K=%d != taps*Cs=%ld", p.K, taps * p.g_Cs);
+    if (p.M % ohw) BAD("M=%d is not a multiple of OH*OW=%ld", p.M, ohw);
+    if (!nchw && p.a_ld < p.g_Cs) BAD("a_ld=%d < Cs=%d", p.a_ld, p.g_Cs);
+    if (kind == KIND_FWD && p.b_ld < p.K) BAD("fwd: b_ld=%d < K=%d", p.b_ld, p.K);
+    if (kind == KIND_DGRAD && ((long)p.b_ld < (taps - 1) * p.b_tapstride + p.N)) BAD("dgrad: b_ld=%d < (taps-1)*tapstride+N", p.b_ld);
+    if (p.epi_mode == EPI_PLAIN && p.c_ld < p.N) BAD("c_ld=%d < N=%d", p.c_ld, p.N);
+  }
+  if (p.a_pro != PRO_NONE && (!p.a_c0 || !p.a_c1)) BAD("A prologue %d without coefficients", p.a_pro);
+  if (p.a_pro == PRO_DZ && (!p.A2 || !p.a_c2)) BAD("BatchNorm-backward prologue without A2 / c2");
+  if (p.b_pro != PRO_NONE && (!p.b_c0 || !p.b_c1)) BAD("B prologue %d without coefficients", p.b_pro);
+  if ((p.a_pro == PRO_SILU_GATE || p.b_pro == PRO_SILU_GATE) && (!p.gate || p.gate_hw <= 0)) BAD("gate prologue without gate tensor");
+  if (p.dact != ACT_NONE && !p.Pre) BAD("act' epilogue without the saved pre-activation");
+  if (p.stat_bwd && p.stat1 && (!p.Z1 || !p.mean1 || !p.invstd1)) BAD("backward statistics without Z1 / mean / invstd");
+  if (p.stat2 && (!p.stat1 || !p.Z2 || !p.mean2 || !p.invstd2)) BAD("second statistics set incomplete");
+  if (p.epi_mode == EPI_TAP_FWD && (!p.tap_out || p.tap_HW <= 0)) BAD("tap epilogue without output / HW");
+  if (p.epi_mode == EPI_TAP_BWD && (!p.tap_dv || p.tap_HW <= 0)) BAD("tap backward epilogue without dv / HW");
+  if (p.Mk && p.mk_ld < p.N) BAD("mask tensor leading dimension %d < N=%d", p.mk_ld, p.N);
+  if (p.R && p.r_ld < p.N) BAD("residual leading dimension %d < N=%d", p.r_ld, p.N);
+  if (p.drop_p < 0.f || p.drop_p >= 1.f) BAD("dropout p=%g outside [0,1)", (double)p.drop_p);
+#undef BAD
+  return MMVQA_OK;
+}
+
 int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MMVQA_OK;
+  if (int r = validate_desc(p, kind, nchw)) return r;
   if (tile != 0 || nchw || !g_tuner) return launch_one(p, kind, nchw, tile, stream);
   const std::string key = tune_key(p, kind, nchw);
   auto it = g_tuner->table.find(key);

@@ -49,6 +49,49 @@ def test_error_reporting_without_gpu():
         L.check(rc)
 
 
+def test_igemm_refuses_inconsistent_descriptors():
+    """misuse returns MMVQA_ERR_ARG on the host instead of reading outside the caller's buffers on the device
+    (the loaders address operands from the descriptor's dimensions alone)"""
+    from mmvqa_amd import _lib as L
+    lib = L.lib()
+
+    def desc():
+        d = L.GemmDesc()
+        d.M, d.N, d.K = 64, 64, 64
+        d.A, d.B, d.C = 0x1000, 0x2000, 0x3000          # never dereferenced: every case below is refused first
+        d.a_ld, d.b_ld, d.c_ld, d.g_Cs = 64, 64, 64, 64
+        d.g_SH = d.g_SW = d.g_OH = d.g_OW = 1
+        d.g_KH = d.g_KW = 1
+        d.g_stride, d.g_pad = 1, 0
+        return d
+
+    def refused(d, kind, what):
+        rc = lib.mmvqa_igemm(C.byref(d), kind, 0, 0, None)
+        assert rc == -1, f"{what}: rc {rc}"
+        assert b"igemm:" in lib.mmvqa_last_error(), what
+
+    d = desc(); d.K = 96                       # K != taps * Cs
+    refused(d, L.KIND_FWD, "K mismatch")
+    d = desc(); d.a_ld = 32                    # rows shorter than the contraction
+    refused(d, L.KIND_FWD, "a_ld")
+    d = desc(); d.b_ld = 8
+    refused(d, L.KIND_FWD, "b_ld")
+    d = desc(); d.A = None
+    refused(d, L.KIND_FWD, "null A")
+    d = desc(); d.a_pro = L.PRO_DZ             # BatchNorm-backward prologue without its second tensor / coefficients
+    refused(d, L.KIND_DGRAD, "PRO_DZ without A2")
+    d = desc(); d.g_KH = d.g_KW = 3; d.g_pad = 1; d.g_SH = d.g_SW = d.g_OH = d.g_OW = 8; d.M = 100   # M not whole images
+    d.K = 9 * 64; d.b_ld = 9 * 64
+    refused(d, L.KIND_FWD, "M not a multiple of OH*OW")
+    d = desc(); d.N = 100                      # wgrad: N != taps * Cs
+    refused(d, L.KIND_WGRAD, "wgrad N")
+    d = desc(); d.dact = L.ACT_GELU            # act' epilogue without the saved pre-activation
+    refused(d, L.KIND_DGRAD, "dact without Pre")
+    d = desc(); d.drop_p = 1.5
+    refused(d, L.KIND_FWD, "dropout p")
+    refused(desc(), 7, "unknown kind")
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from mmvqa_amd import _lib as L
     monkeypatch.setattr(L, "_lib", None)
