@@ -2,12 +2,14 @@
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
-The reference modules that hold these loops cannot be imported in the build image (top-level imports of wandb /
-nltk / pytorch_lightning / sentence_transformers / googletrans / bert_score), so they are restated
-from the source text; every function cites the lines it follows.  Pinning: the arithmetic inside a step (model
-forward, the three losses, Adam) IS pinned by reference-generated fixtures (tests/golden/, oracle/mmbert_oracle.py);
-what this file adds is the ORDER of operations of a step and the bookkeeping around it, which has no fixture
-upstream (the reference has no tests) => "parity unpinned" for the loop order itself, restated line by line.
+Every function cites the reference lines it follows.  PINNED: tests/golden/make_golden_loops.py imports the
+reference's own pretrain/roco_utils.py, models/SupConLoss/supcon_utils.py and vqamed2019/utils.py (packages the image
+lacks -- wandb, nltk, pytorch_lightning, sentence_transformers, googletrans, bert_score, torchvision, timm -- as
+name-only stubs), runs THEIR train_one_epoch functions on the reference Model for two batches and records per-step
+losses, accuracy and the parameters after the two Adam steps (tests/golden/loop_*.npz);
+tests/test_oracle_golden.py::test_loops_match_reference_loops replays them through this file.
+The evaluation half (validate / test) depends on nltk's sentence_bleu, which is absent: BLEU-1 is restated from the
+published algorithm and marked "parity unpinned" below; the bookkeeping around it follows the source text.
 
 A "loader" here is any iterable of batches with the reference's tuple layout (already on the CPU).
 """
@@ -98,3 +100,67 @@ def vqa_train_one_epoch(loader, model, optimizer, criterion, clip=False):
         train_loss.append(loss.detach().cpu().numpy())
     P, T = torch.cat(PREDS).cpu().numpy(), torch.cat(TARGETS).cpu().numpy()
     return np.mean(train_loss), (P == T).mean() * 100., train_loss, PREDS
+
+
+# --------------------------------------------------------------------------- evaluation (vqamed2019/utils.py:690-843)
+def sentence_bleu_unigram(references, hypothesis):
+    """nltk.translate.bleu_score.sentence_bleu(references, hypothesis, weights=[1]) -- third-party (nltk, version
+    unpinned by the reference, absent from the build image): restated from the published algorithm (Papineni et al.
+    2002 as nltk implements it): modified unigram precision with clipping against the references' max counts,
+    closest reference length, brevity penalty exp(1 - r/c) for c <= r, result 0 when no unigram matches.
+    "parity unpinned" (no nltk here): anchored by hand-computed known answers in tests/test_evaluate.py."""
+    import math
+    from collections import Counter
+    counts = Counter(hypothesis)
+    max_counts = {}
+    for ref in references:
+        rc = Counter(ref)
+        for w in counts:
+            max_counts[w] = max(max_counts.get(w, 0), rc[w])
+    numerator = sum(min(c, max_counts[w]) for w, c in counts.items())
+    denominator = max(1, sum(counts.values()))
+    hyp_len = len(hypothesis)
+    ref_len = min((len(r) for r in references), key=lambda rl: (abs(rl - hyp_len), rl))
+    if numerator == 0:
+        return 0
+    if hyp_len > ref_len:
+        bp = 1
+    elif hyp_len == 0:
+        bp = 0
+    else:
+        bp = math.exp(1 - ref_len / hyp_len)
+    return bp * math.exp(math.fsum([1 * math.log(numerator / denominator)]))
+
+
+def calculate_bleu_score(preds, targets, idx2ans):
+    """vqamed2019/utils.py:328-330"""
+    bleu_per_answer = np.asarray([sentence_bleu_unigram([idx2ans[target].split()], idx2ans[pred].split())
+                                  for pred, target in zip(preds, targets)])
+    return np.mean(bleu_per_answer)
+
+
+def vqa_validate(loader, model, criterion, val_category, idx2ans, prefix="val_"):
+    """vqamed2019/utils.py:690-767 (validate, prefix 'val_') and :769-843 (test, prefix ''), args.category unset,
+    args.mixed_precision / args.smoothing False.  val_category = val_df['category'] as a numpy array of strings."""
+    model.eval()
+    val_loss, PREDS, TARGETS = [], [], []
+    with torch.no_grad():
+        for img, question_token, segment_ids, attention_mask, target in loader:
+            logits, _, _ = model(img, question_token, segment_ids, attention_mask)
+            loss = criterion(logits, target)
+            pred = logits.softmax(1).argmax(1).detach()
+            PREDS.append(pred)
+            TARGETS.append(target)
+            val_loss.append(loss.detach().cpu().numpy())
+        val_loss = np.mean(val_loss)
+    PREDS = torch.cat(PREDS).cpu().numpy()
+    TARGETS = torch.cat(TARGETS).cpu().numpy()
+    cat = np.asarray(val_category)
+    names = (("total", None), ("binary", "binary"), ("plane", "plane"), ("organ", "organ"), ("modality", "modality"),
+             ("abnorm", "abnormality"))
+    acc, bleu = {}, {}
+    for short, c in names:
+        sel = slice(None) if c is None else (cat == c)
+        acc[prefix + short + "_acc"] = np.round((PREDS[sel] == TARGETS[sel]).mean() * 100., 4)
+        bleu[prefix + short + "_bleu"] = np.round(calculate_bleu_score(PREDS[sel], TARGETS[sel], idx2ans), 4)
+    return val_loss, PREDS, acc, bleu

@@ -108,3 +108,81 @@ def test_vqa_loop_matches_oracle_loop(loss_name, clip):
         assert abs(float(loss) - float(ref_losses[i])) <= 1e-3 * abs(float(ref_losses[i])), (i, float(loss), float(ref_losses[i]))
         assert torch.equal(pred.cpu(), ref_preds[i])
     check_param_deltas(orc, hip, before)
+
+
+# ----------------------------------------------------------------------------- replay of the REFERENCE's own loops
+def _fixture_model(golden_dir, tag, tm, ds, supcon):
+    import os
+    import numpy as np
+    from test_oracle_golden import model_case_args
+    g = dict(np.load(os.path.join(golden_dir, tag + ".npz"), allow_pickle=False))
+    B, T, hw, V = [int(v) for v in g["dims"]]
+    args = O.make_args(**model_case_args(tm, ds, supcon, "resnet152", False, V, emb_dropout_prob=0.0, rf_dropout_prob=0.0,
+                                         emb_vocab=V))
+    torch.manual_seed(int(g["seed"]))
+    orc = O.OracleModel(args)                       # the seeded weights the reference loop started from
+    hip = mmvqa_amd.Model(args)
+    hip.load_state_dict(orc.state_dict())
+    hip.to(dev()).train()
+    return g, hip
+
+
+def _check_after(hip, g, lr):
+    hp = dict(hip.named_parameters())
+    n = 0
+    for k in g:
+        if not k.startswith("p_"):
+            continue
+        name = k[2:].replace("__", ".")
+        got = hp[name].detach().flatten().cpu()
+        if got.numel() > 4096:
+            got = got[:: max(1, got.numel() // 4096)][:4096]
+        off = ((got - torch.from_numpy(g[k])).abs() > 0.5 * lr).float().mean().item()
+        assert off <= 0.03, f"{name}: {off:.3f} of the sampled elements differ from the reference after two steps"
+        n += 1
+    assert n >= 14
+    sd = hip.state_dict()
+    assert int(sd["transformer.trans.model.bn1.num_batches_tracked"]) == int(g["b_transformer__trans__model__bn1__num_batches_tracked"])
+    rm = sd["transformer.trans.model.bn1.running_mean"].cpu()
+    ref = torch.from_numpy(g["b_transformer__trans__model__bn1__running_mean"])
+    assert float((rm - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
+
+
+def test_reference_loop_fixtures_replay(golden_dir):
+    """fixtures recorded from the reference's OWN train_one_epoch functions (tests/golden/make_golden_loops.py):
+    train.py's step functions reproduce the per-step losses and the parameters after two Adam steps"""
+    tg = lambda g, k: torch.from_numpy(g[k]).to(dev())   # noqa: E731
+    # MLM (pretrain/roco_utils.py:207-290)
+    g, hip = _fixture_model(golden_dir, "loop_mlm", "transformer", "roco", False)
+    lr = float(g["lr"])
+    opt, red = mmvqa_amd.FusedAdam(hip, lr=lr), GradReducer(hip.flat_grads)
+    nm = nc = 0.0
+    for i in range(2):
+        b = tuple(tg(g, f"{n}{i}") for n in ("img", "ids", "seg", "mask", "tgt"))
+        loss, pred, stats = train.mlm_step(hip, opt, red, 1, b)
+        assert abs(float(loss) - float(g["losses"][i])) <= 1e-3 * abs(float(g["losses"][i])), (i, float(loss))
+        s = stats.tolist()
+        nm, nc = nm + s[1], nc + s[2]
+    assert abs(100.0 * nc / nm - float(g["total_acc"])) < 1e-9
+    _check_after(hip, g, lr)
+    # MLM + SupCon (models/SupConLoss/supcon_utils.py:263-323)
+    g, hip = _fixture_model(golden_dir, "loop_supcon", "realformer", "roco", True)
+    opt, red = mmvqa_amd.FusedAdam(hip, lr=lr), GradReducer(hip.flat_grads)
+    for i in range(2):
+        batch = train.process_tensors((tg(g, f"img_a{i}"), tg(g, f"img_b{i}")), tg(g, f"ids_a{i}"), tg(g, f"ids_b{i}"),
+                                      tg(g, f"seg{i}"), tg(g, f"mask{i}"), tg(g, f"tgt_a{i}"), tg(g, f"tgt_b{i}"))
+        loss, _, _ = train.supcon_step(hip, opt, red, 1, batch)
+        want = float(g["losses_mlm"][i] + g["losses_supcon"][i])
+        assert abs(float(loss) - want) <= 1e-3 * abs(want), (i, float(loss), want)
+    _check_after(hip, g, lr)
+    # VQA-Med + ASL (vqamed2019/utils.py:625-688)
+    g, hip = _fixture_model(golden_dir, "loop_vqa", "realformer", "VQA-Med", False)
+    opt, red = mmvqa_amd.FusedAdam(hip, lr=lr), GradReducer(hip.flat_grads)
+    preds = []
+    for i in range(2):
+        b = tuple(tg(g, f"{n}{i}") for n in ("img", "ids", "seg", "mask", "tgt"))
+        loss, pred = train.vqa_step(hip, opt, red, 1, b, mmvqa_amd.asl_loss)
+        assert abs(float(loss) - float(g["losses"][i])) <= 1e-3 * abs(float(g["losses"][i])), (i, float(loss))
+        preds.append(pred.cpu())
+    assert torch.equal(torch.cat(preds), torch.from_numpy(g["preds"]))
+    _check_after(hip, g, lr)

@@ -205,3 +205,69 @@ def test_loop_restatement_first_step_equals_reference_loss(golden_dir):
             _, _, losses, _ = LO.vqa_train_one_epoch([batch, batch], m, opt, O.asl_single_label)
         close(losses[0], g["loss"], 2e-5, tag + " first-step loss")
         assert float(losses[1]) < float(losses[0])
+
+
+# ----------------------------------------------------------------------------- a20: the REFERENCE's own step loops
+def loop_model(g, tm, ds, supcon):
+    B, T, hw, V = [int(v) for v in g["dims"]]
+    torch.manual_seed(int(g["seed"]))
+    m = O.OracleModel(O.make_args(**model_case_args(tm, ds, supcon, "resnet152", False, V)))
+    assert abs(wsum(m.state_dict()) - float(g["wsum"])) < 1e-6 * float(g["wsum"]), "RNG drift"
+    zero_dropout(m)
+    return m
+
+
+def check_params_after(named, g, lr, frac=0.02):
+    """parameters after the two optimizer steps vs the reference's: Adam moves an element by ~lr*sign(g) at first, so
+    an element whose gradient is ~0 may land lr away; all but a small fraction must agree to a fraction of lr"""
+    n = 0
+    for k in g:
+        if not k.startswith("p_"):
+            continue
+        name = k[2:].replace("__", ".")
+        got = named[name].detach().flatten().cpu()
+        if got.numel() > 4096:
+            got = got[:: max(1, got.numel() // 4096)][:4096]
+        off = ((got - t(g[k])).abs() > 0.25 * lr).float().mean().item()
+        assert off <= frac, f"{name}: {off:.3f} of the sampled elements differ from the reference after two steps"
+        n += 1
+    assert n >= 14
+
+
+def test_loops_match_reference_loops(golden_dir):
+    """oracle/loops_oracle.py against fixtures recorded from the reference's own train_one_epoch functions
+    (tests/golden/make_golden_loops.py): per-step losses, epoch mean, accuracy, parameters after two Adam steps"""
+    from oracle import loops_oracle as LO
+    # --- MLM: pretrain/roco_utils.py:207-290
+    g = load(golden_dir, "loop_mlm")
+    m = loop_model(g, "transformer", "roco", False)
+    loader = [tuple(t(g[f"{n}{i}"]) for n in ("img", "ids", "seg", "mask", "tgt")) for i in range(2)]
+    opt = torch.optim.Adam(m.parameters(), lr=float(g["lr"]))
+    mean_loss, acc, losses, _ = LO.mlm_train_one_epoch(loader, m, torch.nn.NLLLoss(), opt)
+    close(np.array([float(x) for x in losses]), g["losses"], 2e-5, "mlm step losses")
+    close(mean_loss, g["mean_loss"], 2e-5, "mlm mean loss")
+    assert abs(float(acc) - float(g["total_acc"])) < 1e-9
+    check_params_after(dict(m.named_parameters()), g, float(g["lr"]))
+    close(m.state_dict()["transformer.trans.model.bn1.running_mean"], g["b_transformer__trans__model__bn1__running_mean"], 1e-5, "bn1 running mean after 2 steps")
+    assert int(m.state_dict()["transformer.trans.model.bn1.num_batches_tracked"]) == int(g["b_transformer__trans__model__bn1__num_batches_tracked"]) == 10
+    # --- MLM + SupCon: models/SupConLoss/supcon_utils.py:263-323
+    g = load(golden_dir, "loop_supcon")
+    m = loop_model(g, "realformer", "roco", True)
+    loader = [((t(g[f"img_a{i}"]), t(g[f"img_b{i}"])), t(g[f"ids_a{i}"]), t(g[f"ids_b{i}"]), t(g[f"seg{i}"]), t(g[f"mask{i}"]),
+               t(g[f"tgt_a{i}"]), t(g[f"tgt_b{i}"])) for i in range(2)]
+    opt = torch.optim.Adam(m.parameters(), lr=float(g["lr"]))
+    mean_loss, acc, losses, _ = LO.supcon_train_one_epoch(loader, m, torch.nn.NLLLoss(), O.supcon_simclr, opt)
+    close(np.array([float(x) for x in losses]), g["losses_mlm"] + g["losses_supcon"], 5e-5, "supcon step losses")
+    close(mean_loss, g["mean_loss"], 5e-5, "supcon mean loss")
+    assert abs(float(acc) - float(g["total_acc"])) < 1e-9
+    check_params_after(dict(m.named_parameters()), g, float(g["lr"]))
+    # --- VQA-Med + ASL: vqamed2019/utils.py:625-688
+    g = load(golden_dir, "loop_vqa")
+    m = loop_model(g, "realformer", "VQA-Med", False)
+    loader = [tuple(t(g[f"{n}{i}"]) for n in ("img", "ids", "seg", "mask", "tgt")) for i in range(2)]
+    opt = torch.optim.Adam(m.parameters(), lr=float(g["lr"]))
+    mean_loss, acc, losses, preds = LO.vqa_train_one_epoch(loader, m, opt, O.asl_single_label)
+    close(np.array([float(x) for x in losses]), g["losses"], 2e-5, "vqa step losses")
+    assert np.array_equal(torch.cat(preds).numpy(), g["preds"])
+    assert abs(float(acc) - float(g["total_acc"])) < 1e-9
+    check_params_after(dict(m.named_parameters()), g, float(g["lr"]))
