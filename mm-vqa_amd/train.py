@@ -26,7 +26,7 @@ import torch
 import torch.distributed as dist
 from torch.optim import lr_scheduler
 
-from . import FusedAdam, Model, asl_loss, mlm_loss, split_feat, supcon_loss, synth
+from . import FusedAdam, Model, asl_loss, checkpoint, mlm_loss, split_feat, supcon_loss, synth
 from .ddp import GradReducer, global_supcon_views
 
 
@@ -54,6 +54,10 @@ def common_args(p):
     p.add_argument("--image_size", type=int, default=224)
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--state_dict", type=str, default=None, help="local checkpoint to start from")
+    p.add_argument("--backbone_weights", type=str, default=None,
+                   help="local torchvision resnet152 / timm tf_efficientnetv2_m state_dict (what pretrained=True fetches, image_encoding.py:20-26)")
+    p.add_argument("--bert_weights", type=str, default=None,
+                   help="local HF bert-base-uncased state_dict: its embeddings are used (mmbert.py:52-56)")
     # reduced backbones for smoke tests
     p.add_argument("--resnet_layers", type=int, nargs=4, default=[3, 8, 36, 3])
     p.add_argument("--resnet_width", type=int, default=64)
@@ -83,12 +87,20 @@ class Ctx:
 def build(args, ctx, n_classes=None):
     torch.manual_seed(args.seed)          # identical replicas
     model = Model(args)
+    if args.backbone_weights:
+        checkpoint.load_backbone(model, args.backbone_weights)
+    if args.bert_weights:
+        checkpoint.load_bert_embeddings(model, args.bert_weights)
     if args.state_dict:
-        sd = torch.load(args.state_dict, map_location="cpu")
+        sd = checkpoint.read_state_dict(args.state_dict)
         own = model.state_dict()
         model.load_state_dict({k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}, strict=False)
+    if getattr(args, "use_pretrained", False):          # vqamed2019/train.py:125-135
+        checkpoint.load_roco_pretrained(model, args.model_dir)
     if n_classes is not None:              # vqamed2019/train.py:137,141,149
         model.classifier[2] = torch.nn.Linear(args.hidden_size, n_classes)
+    if getattr(args, "resume_training", False):         # vqamed2019/train.py:139-144
+        checkpoint.load_model(model, args.resume_dir)
     model.to(ctx.dev)
     model.set_seed(args.seed + ctx.rank)
     opt = FusedAdam(model, lr=args.lr)
@@ -341,6 +353,10 @@ def main(argv=None):
         p.add_argument("--num_classes", type=int, default=1552)
         p.add_argument("--counter", type=int, default=20)
         p.add_argument("--clip", action="store_true", default=False, help="clip_grad_norm_(1.0), utils.py:663-664")
+        p.add_argument("--use_pretrained", action="store_true", default=False)      # vqamed2019/train.py:69-72
+        p.add_argument("--model_dir", type=str, default=None, help="ROCO-pretrained Model state_dict")
+        p.add_argument("--resume_training", action="store_true", default=False)
+        p.add_argument("--resume_dir", type=str, default=None, help="fine-tuned Model state_dict to continue from")
     args = p.parse_args(argv)
     out = {"mlm": run_mlm, "supcon": run_supcon, "vqa": run_vqa}[mode](args)
     if dist.is_initialized():
