@@ -36,6 +36,7 @@ struct FastDiv {  // q = n / d for 0 <= n < 2^31 (host-computed magic; CUTLASS F
 struct GemmAux {
   FastDiv ohw, ow;
   int fast;   // 0: general loaders | 1: uniform-tap loaders | 2: uniform-tap loaders with a halo mask (host-decided)
+  int stagger;   // 8-wave variant: the second wave group runs its VALU/LDS-write block first (0 = off, for A/B timing)
 };
 
 __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
@@ -807,7 +808,15 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
       constexpr int SV = SB - (NS >= 32 ? 5 : 3);   // fast loaders: the slot of the single VALU block (its LDS writes land before the barrier)
       constexpr int FLS = (SV - 2) / NC > 0 ? (SV - 2) / NC : 1;
       static_assert(2 + (NC - 1) * FLS < SV, "fast load slots must precede the VALU slot");
-      auto body = [&](int t, Stage& Sload, Stage& Sstore) __attribute__((always_inline)) {
+      static_assert(2 + (NC - 1) * FLS + 1 < NS, "staggered group: advance/halo slot inside the K-tile");
+      // STG (8-wave variant, second group of four waves): the two waves of a SIMD run the same program between the
+      // same barriers, so they reach their MFMA runs and their VALU/LDS-write blocks together and contend for the
+      // same unit (MI355X_MICROARCH.md "Two waves per SIMD", item 9).  The second group therefore does its VALU block
+      // (prologue math + LDS writes of tile t+1) at the START of the interval, while the first group is in its MFMAs,
+      // and its MFMAs while the first group writes: same work, same barriers, bit-identical results.
+      auto body = [&](auto STG_T, int t, Stage& Sload, Stage& Sstore) __attribute__((always_inline)) {
+        constexpr bool STG = decltype(STG_T)::value;
+        constexpr int SVX = STG ? 1 : SV;
         const int buf = t & 1;
         const float* as = As + buf * A_TILE;
         const float* bs = Bs + buf * B_TILE;
@@ -838,7 +847,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
           if constexpr (FAST != 0) {
             // scalars in slot 1, then one buffer_load every FLS-th slot, all issued before the VALU slot SV
             if constexpr (sl == 1) f_scalars(Sload);
-            if constexpr (sl >= 2 && sl < SV && (sl - 2) % FLS == 0 && (sl - 2) / FLS < NC) f_chunk(Sload, (sl - 2) / FLS);
+            if constexpr (sl >= 2 && (STG || sl < SV) && (sl - 2) % FLS == 0 && (sl - 2) / FLS < NC) f_chunk(Sload, (sl - 2) / FLS);
           } else {
             if constexpr (sl >= L0 && (sl - L0) % LSTR == 0 && (sl - L0) / LSTR < NLP)
               LP(Sload, kt_begin + t + 2, (sl - L0) / LSTR);   // past the end everything is masked
@@ -846,7 +855,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
 #endif
 #ifndef EXP_NOSTORE
 #ifdef IGEMM_TRACE
-          if constexpr (sl == SV && FAST != 0) {   // time the wait for the whole stage that is about to be written to LDS
+          if constexpr (sl == SVX && FAST != 0) {   // time the wait for the whole stage that is about to be written to LDS
             constexpr int NLD = (A_ROWK && (A_AFF || A_TWO) ? (APRO == PRO_DZ ? 3 : 2) : 0) + NAC * (A_TWO ? 2 : 1) + NBC;
             const unsigned long long ta = __builtin_readcyclecounter();
             __builtin_amdgcn_s_waitcnt(0x0F70 | (NLD & 15) | ((NLD >> 4) << 14));   // vmcnt(NLD): this body's own loads stay in flight
@@ -858,9 +867,17 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
             // ONE vector-ALU block per K-tile (a VALU instruction costs ~4 cycles inside a run but ~10 when
             // sprinkled between MFMAs: tools/mfma_tile_budget.hip): the prologue math + LDS writes of tile t+1,
             // then the position advance and the halo masks of the tile this register stage receives next
-            if constexpr (sl == SV) {
+            if constexpr (sl == SVX) {
 #pragma unroll
               for (int c = 0; c < NC; ++c) fstore_chunk(Sstore, buf ^ 1, c);
+              if constexpr (!STG) {
+                f_advance();
+                f_halo(Sstore);
+              }
+            }
+            // staggered group: the position advance and the halo masks of the NEXT tile come after this tile's loads
+            // have been issued (f_halo rewrites the effective offsets those loads use)
+            if constexpr (STG && sl == 2 + (NC - 1) * FLS + 1) {
               f_advance();
               f_halo(Sstore);
             }
@@ -874,12 +891,22 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
       };
       // pairs only inside the loop (a conditional second half would add a head <- first-half path on which
       // the first stage's loads are still in flight: the wait-count pass then drains everything at the head)
+      using STG0 = std::integral_constant<bool, false>;
+      using STG1 = std::integral_constant<bool, true>;
       int t = 0;
-      for (; t + 1 < nkt; t += 2) {
-        body(t, S0, S1);
-        body(t + 1, S1, S0);
+      if (KS == 2 && FAST != 0 && ks == 1 && x.stagger) {
+        for (; t + 1 < nkt; t += 2) {
+          body(STG1{}, t, S0, S1);
+          body(STG1{}, t + 1, S1, S0);
+        }
+        if (t < nkt) body(STG1{}, t, S0, S1);
+      } else {
+        for (; t + 1 < nkt; t += 2) {
+          body(STG0{}, t, S0, S1);
+          body(STG0{}, t + 1, S1, S0);
+        }
+        if (t < nkt) body(STG0{}, t, S0, S1);
       }
-      if (t < nkt) body(t, S0, S1);
     } else {
       // large wave tiles (16-64 MFMAs per k-group, two workgroups per CU): plain order, the second
       // resident workgroup covers the LDS-write/barrier bubble
@@ -1286,6 +1313,8 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
   x.ow = make_fastdiv(p.g_OW);
   // uniform-tap loaders: a K-tile never straddles a filter tap, nothing ragged, 31-bit byte offsets
   x.fast = 0;
+  static const int stagger_on = getenv("MMVQA_IGEMM_NOSTAGGER") ? 0 : 1;
+  x.stagger = stagger_on;
   if (!NCHW && (p.K % BK == 0 || (KIND == KIND_WGRAD && p.pixmask)) && !p.gate && !getenv("MMVQA_IGEMM_GENERAL")) {
     const int taps = p.g_KH * p.g_KW;
     const double lim = 2147483648.0 - 16777216.0;
