@@ -277,6 +277,43 @@ int mmvqa_engine_profile_read(mmvqa_engine* e, int cls, long long* launches, dou
 int mmvqa_engine_profile_read_region(mmvqa_engine* e, int region, int cls, long long* launches, double* ms,
                                      double* flops);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Device input pipeline: the torchvision/PIL transforms of pretrain/roco_train.py:98-112 and
+ * vqamed2019/train.py:179-200 on decoded uint8 RGB images in HBM, bit-exact with Pillow's arithmetic.
+ * One job = PIL crop(box) -> resize((rw, rh), BILINEAR) -> keep the out_w x out_h window at (ox, oy):
+ *   Resize(224)+CenterCrop(224): box = whole image, (rw, rh) = resized size, (ox, oy) = crop offset
+ *   RandomResizedCrop          : box = sampled crop, (rw, rh) = (224, 224), (ox, oy) = (0, 0)
+ * All pointers are device pointers; coefficient tables come from mmvqa_resample_coeffs (host) copied to the device. */
+typedef struct mmvqa_resample_job {
+  const unsigned char* src; int sh, sw, spitch;   /* source image, HWC uint8, row pitch in bytes */
+  int bx, by, bw, bh;                             /* box of the source that is resized */
+  int rw, rh;                                     /* size the box is resized to */
+  int ox, oy;                                     /* window of the resized image that is produced */
+  int ty0, tyn;                                   /* box rows [ty0, ty0+tyn) the vertical pass of the window reads */
+  unsigned char* tmp;                             /* scratch [tyn][out_w][3] */
+  unsigned char* dst; int dpitch;                 /* output [out_h][out_w][3] */
+  const int* hb; const int* hk; int hks;          /* horizontal bounds [rw][2] / coefficients [rw][hks] */
+  const int* vb; const int* vk; int vks;          /* vertical   bounds [rh][2] / coefficients [rh][vks] */
+} mmvqa_resample_job;
+size_t mmvqa_sizeof_resample_job(void);
+/* HOST function: Pillow's bilinear resampling coefficients (Resample.c precompute_coeffs + normalize_coeffs_8bpc) of
+ * resizing source range [in0, in1) of an axis of in_size pixels to out_size; returns taps per output (ksize);
+ * with bounds == NULL only the size is returned */
+int mmvqa_resample_coeffs(int in_size, double in0, double in1, int out_size, int* bounds, int* kk, int ksize_cap);
+int mmvqa_aug_resample(mmvqa_stream_t s, const mmvqa_resample_job* jobs_dev, int njobs, int max_tmp_rows, int out_h,
+                       int out_w);
+/* Image.rotate(angle, NEAREST, expand=False, fillcolor=0) on [B][H][W][3]: fix_dev[b][6] = the 16.16 fixed-point
+ * affine coefficients a0..a5 of Geometry.c affine_fixed (computed by the host side from the angle) */
+int mmvqa_aug_rotate(mmvqa_stream_t s, const unsigned char* src, unsigned char* dst, const int* fix_dev, int B, int H,
+                     int W);
+/* one ColorJitter round in place: image b applies op_dev[b] (0 brightness, 1 contrast, 2 saturation, 3 hue with
+ * factor = the uint8 hue shift, < 0 none) with factor_dev[b]; lsum_dev = B uint64 of scratch (L sums for contrast) */
+int mmvqa_aug_jitter_round(mmvqa_stream_t s, unsigned char* img, const int* op_dev, const float* factor_dev,
+                           unsigned long long* lsum_dev, int B, int npix);
+/* ToTensor + Normalize: uint8 [B][npix][3] -> fp32 [B][3][npix], (x/255 - mean)/std; mean3/std3 are HOST pointers */
+int mmvqa_aug_to_tensor(mmvqa_stream_t s, const unsigned char* img, float* out, int B, int npix, const float* mean3,
+                        const float* std3);
+
 #ifdef __cplusplus
 }
 #endif

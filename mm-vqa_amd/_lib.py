@@ -56,6 +56,17 @@ class AttnDesc(C.Structure):
     ]
 
 
+class ResampleJob(C.Structure):
+    """mirror of mmvqa_resample_job"""
+    _fields_ = [
+        ("src", c_ptr), ("sh", C.c_int), ("sw", C.c_int), ("spitch", C.c_int),
+        ("bx", C.c_int), ("by", C.c_int), ("bw", C.c_int), ("bh", C.c_int),
+        ("rw", C.c_int), ("rh", C.c_int), ("ox", C.c_int), ("oy", C.c_int), ("ty0", C.c_int), ("tyn", C.c_int),
+        ("tmp", c_ptr), ("dst", c_ptr), ("dpitch", C.c_int),
+        ("hb", c_ptr), ("hk", c_ptr), ("hks", C.c_int), ("vb", c_ptr), ("vk", c_ptr), ("vks", C.c_int),
+    ]
+
+
 class ModelDesc(C.Structure):
     """mirror of mmvqa_model_desc"""
     _fields_ = [
@@ -100,6 +111,12 @@ SIGNATURES = {
     "mmvqa_colsum": (_i, [_P, _P, _i, _i, _i, _P]),
     "mmvqa_dropout": (_i, [_P, _P, _l, _f, _u32]),
     "mmvqa_pixmask": (_i, [_P, _P] + [_i] * 9),
+    "mmvqa_sizeof_resample_job": (_sz, []),
+    "mmvqa_resample_coeffs": (_i, [_i, _d, _d, _i, _P, _P, _i]),
+    "mmvqa_aug_resample": (_i, [_P, _P, _i, _i, _i, _i]),
+    "mmvqa_aug_rotate": (_i, [_P, _P, _P, _P, _i, _i, _i]),
+    "mmvqa_aug_jitter_round": (_i, [_P, _P, _P, _P, _P, _i, _i]),
+    "mmvqa_aug_to_tensor": (_i, [_P, _P, _P, _i, _i, _P, _P]),
     "mmvqa_engine_create": (_i, [C.POINTER(ModelDesc), C.POINTER(_P)]),
     "mmvqa_engine_destroy": (None, [_P]),
     "mmvqa_engine_num_tensors": (_i, [_P]),
@@ -140,7 +157,12 @@ def lib():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    for nm, st in (("gemm", GemmDesc), ("attn", AttnDesc), ("model", ModelDesc)):
+    for nm, st in (("gemm", GemmDesc), ("attn", AttnDesc), ("model", ModelDesc), ("resample_job", ResampleJob)):
+        if nm == "resample_job":
+            got = L.mmvqa_sizeof_resample_job()
+            if got != C.sizeof(st):
+                raise MMVQAError(f"ABI mismatch: sizeof(mmvqa_resample_job) = {got} in the library, {C.sizeof(st)} in Python")
+            continue
         got = getattr(L, f"mmvqa_sizeof_{nm}_desc")()
         if got != C.sizeof(st):
             raise MMVQAError(f"ABI mismatch: sizeof(mmvqa_{nm}_desc) = {got} in the library, {C.sizeof(st)} in Python")
