@@ -321,7 +321,10 @@ class Model(nn.Module):
         rows = B * T if d.head_kind == 0 else B
         V = d.n_classes
         ld = (V + 3) & ~3
-        buf = torch.zeros(rows, ld, dtype=torch.float32, device=img.device)
+        # (pad columns V..ld-1 are never read: the loss kernels mask them and the engine's GEMMs contract over V)
+        buf = torch.empty(rows, ld, dtype=torch.float32, device=img.device)
+        if ld != V:
+            buf[:, V:].zero_()
         feat = torch.empty(B, d.feat_dim, dtype=torch.float32, device=img.device) if d.supcon else None
         self._seed_ctr = (self._seed_ctr * 1103515245 + 12345) & 0x7FFFFFFF
         L.check(L.lib().mmvqa_engine_forward(self._handle, L.stream_ptr(), L.ptr(img), L.ptr(ids), L.ptr(seg),
