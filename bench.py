@@ -247,7 +247,7 @@ def main():
     # Roofline of the dominant kernel class: one more step, identical to the timed ones (same two HIP streams), with
     # a HIP event pair around every launch recorded on the stream that launch goes to.  The weight-gradient GEMMs
     # run beside the data-gradient chain, so a launch's duration includes the time it shares the chip: the average
-    # agrees with the steady-state rocprofv3 kernel trace (profiles/round1_c_kernel_stats_steady_cfg2.csv).
+    # agrees with the steady-state rocprofv3 kernel trace (profiles/round2_kernel_stats_steady_cfg2.csv).
     roof = None
     if not a.no_roofline:
         model.profile(True)
@@ -265,10 +265,12 @@ def main():
         model.profile(False)
         ach_alone = gs["flops"] / (gs["ms"] * 1e-3) / 1e12 if gs["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "round1_igemm_traffic.json")
-        if CONFIG == 2 and os.path.exists(tf):   # HBM bytes per launch from the committed rocprofv3 PMC passes
-            traffic = json.load(open(tf))["igemm"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/round1_igemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)"
+        for name in ("round2_igemm_traffic.json", "round1_igemm_traffic.json"):
+            tf = os.path.join(ROOT, "profiles", name)
+            if CONFIG == 2 and os.path.exists(tf):   # HBM bytes per launch from the committed rocprofv3 PMC passes
+                traffic = json.load(open(tf))["igemm"]["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)"
+                break
         roof = dict(bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src, kernel="igemm_kernel (fp32 MFMA implicit GEMM)",
                     launches_per_step=g["launches"], avg_launch_us=g["ms"] * 1e3 / max(1, g["launches"]),
