@@ -217,6 +217,31 @@ int mmvqa_l2norm_bwd(mmvqa_stream_t s, const float* dy, const float* y, const fl
  * data-parallel job, SURVEY 8(e) collective 2). */
 int mmvqa_supcon_loss(mmvqa_stream_t s, const float* f, float* loss, float* df, float* ws, int N, int D, float temp,
                       float base_temp, float gscale);
+/* ---- EfficientNetV2 (timm tf_efficientnetv2_m as models/image_encoding.py:15,26,100-115 instantiates it) pieces,
+ * NHWC fp32; sc/sh = BatchNorm scale/shift of the producing conv (applied on load), stat = [16][C][2] doubles.
+ * depthwise 3x3 (MBConv conv_dw): z2 = dw(silu(z1*s1+b1)), statistics of z2; TF "SAME" padding via pad (begin) */
+int mmvqa_dwconv_fwd(mmvqa_stream_t s, const float* z1, const float* s1, const float* b1, const float* w, float* z2,
+                     double* stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad);
+/* g1 = dw^T(P*g2 + Q*z2 + R) * silu'(z1*s1+b1); BatchNorm-backward sums of bn1 (sum g1, sum g1*xhat1) */
+int mmvqa_dwconv_bwd_data(mmvqa_stream_t s, const float* g2, const float* z2, const float* P, const float* Q,
+                          const float* R, const float* w, const float* z1, const float* s1, const float* b1,
+                          const float* mean1, const float* invstd1, float* g1, double* stat, int N, int H, int W, int C,
+                          int OH, int OW, int stride, int pad);
+/* dw[c][tap] += sum_pix (P*g2 + Q*z2 + R)[pix,c] * silu(z1*s1+b1)[pix@tap,c] */
+int mmvqa_dwconv_bwd_weight(mmvqa_stream_t s, const float* g2, const float* z2, const float* P, const float* Q,
+                            const float* R, const float* z1, const float* s1, const float* b1, float* dw, int N, int H,
+                            int W, int C, int OH, int OW, int stride, int pad);
+/* squeeze-excite: pool[n][c] = mean_hw silu(z*sc+sh); dgate[n][c] = sum_hw t * silu(z*sc+sh) */
+int mmvqa_se_pool(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, float* pool, int N, int HW, int C);
+int mmvqa_se_dgate(mmvqa_stream_t s, const float* t, const float* z, const float* sc, const float* sh, float* dgate,
+                   int N, int HW, int C);
+/* out = (t * gate[n][c] + add[n][c] / HW) * act'(z*sc+sh) (gate/add nullable); BatchNorm-backward sums into stat */
+int mmvqa_act_bwd_stats(mmvqa_stream_t s, const float* t, const float* gate, const float* add, const float* z,
+                        const float* sc, const float* sh, const float* mean, const float* invstd, int act, float* out,
+                        double* stat, long npix, int HW, int C);
+/* block end: out = post(pre(z*sc+sh) + idn'), idn' = idn | iact(idn*ids+idb) | nothing */
+int mmvqa_bn_act_add(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, int pre_act, const float* idn,
+                     const float* ids, const float* idb, int idn_act, int post_act, float* out, long rows, int C);
 /* torch.optim.Adam defaults over a flat buffer; g is scaled by gscale first and zeroed when zero_grad != 0 */
 int mmvqa_adam(mmvqa_stream_t s, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2,
                double eps, int step, float gscale, int zero_grad);

@@ -106,6 +106,13 @@ SIGNATURES = {
     "mmvqa_l2norm_fwd": (_i, [_P, _P, _P, _P, _i, _i]),
     "mmvqa_l2norm_bwd": (_i, [_P, _P, _P, _P, _P, _i, _i]),
     "mmvqa_supcon_loss": (_i, [_P, _P, _P, _P, _P, _i, _i, _f, _f, _f]),
+    "mmvqa_dwconv_fwd": (_i, [_P, _P, _P, _P, _P, _P, _P] + [_i] * 8),
+    "mmvqa_dwconv_bwd_data": (_i, [_P] * 14 + [_i] * 8),
+    "mmvqa_dwconv_bwd_weight": (_i, [_P] * 10 + [_i] * 8),
+    "mmvqa_se_pool": (_i, [_P, _P, _P, _P, _P, _i, _i, _i]),
+    "mmvqa_se_dgate": (_i, [_P, _P, _P, _P, _P, _P, _i, _i, _i]),
+    "mmvqa_act_bwd_stats": (_i, [_P] * 9 + [_i, _P, _P, _l, _i, _i]),
+    "mmvqa_bn_act_add": (_i, [_P, _P, _P, _P, _i, _P, _P, _P, _i, _i, _P, _l, _i]),
     "mmvqa_adam": (_i, [_P, _P, _P, _P, _P, _l, _d, _d, _d, _d, _i, _f, _i]),
     "mmvqa_axpy": (_i, [_P, _P, _P, _f, _l]),
     "mmvqa_colsum": (_i, [_P, _P, _i, _i, _i, _P]),

@@ -139,6 +139,37 @@ int mmvqa_supcon_loss(mmvqa_stream_t s, const float* f, float* loss, float* df, 
                       float base_temp, float gscale) {
   return k_supcon(ST(s), f, loss, df, ws, N, D, temp, base_temp, gscale);
 }
+int mmvqa_dwconv_fwd(mmvqa_stream_t s, const float* z1, const float* s1, const float* b1, const float* w, float* z2,
+                     double* stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad) {
+  return k_dwconv_fwd(ST(s), z1, s1, b1, w, z2, stat, N, H, W, C, OH, OW, stride, pad);
+}
+int mmvqa_dwconv_bwd_data(mmvqa_stream_t s, const float* g2, const float* z2, const float* P, const float* Q,
+                          const float* R, const float* w, const float* z1, const float* s1, const float* b1,
+                          const float* mean1, const float* invstd1, float* g1, double* stat, int N, int H, int W, int C,
+                          int OH, int OW, int stride, int pad) {
+  return k_dwconv_bwd_data(ST(s), g2, z2, P, Q, R, w, z1, s1, b1, mean1, invstd1, g1, stat, N, H, W, C, OH, OW, stride, pad);
+}
+int mmvqa_dwconv_bwd_weight(mmvqa_stream_t s, const float* g2, const float* z2, const float* P, const float* Q,
+                            const float* R, const float* z1, const float* s1, const float* b1, float* dw, int N, int H,
+                            int W, int C, int OH, int OW, int stride, int pad) {
+  return k_dwconv_bwd_weight(ST(s), g2, z2, P, Q, R, z1, s1, b1, dw, N, H, W, C, OH, OW, stride, pad);
+}
+int mmvqa_se_pool(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, float* pool, int N, int HW, int C) {
+  return k_se_pool(ST(s), z, sc, sh, pool, N, HW, C);
+}
+int mmvqa_se_dgate(mmvqa_stream_t s, const float* t, const float* z, const float* sc, const float* sh, float* dgate,
+                   int N, int HW, int C) {
+  return k_se_dgate(ST(s), t, z, sc, sh, dgate, N, HW, C);
+}
+int mmvqa_act_bwd_stats(mmvqa_stream_t s, const float* t, const float* gate, const float* add, const float* z,
+                        const float* sc, const float* sh, const float* mean, const float* invstd, int act, float* out,
+                        double* stat, long npix, int HW, int C) {
+  return k_act_bwd_stats(ST(s), t, gate, add, z, sc, sh, mean, invstd, act, out, stat, npix, HW, C);
+}
+int mmvqa_bn_act_add(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, int pre_act, const float* idn,
+                     const float* ids, const float* idb, int idn_act, int post_act, float* out, long rows, int C) {
+  return k_bn_act_add(ST(s), z, sc, sh, pre_act, idn, ids, idb, idn_act, post_act, out, rows, C);
+}
 int mmvqa_adam(mmvqa_stream_t s, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2,
                double eps, int step, float gscale, int zero_grad) {
   return k_adam(ST(s), p, g, m, v, n, lr, b1, b2, eps, step, gscale, zero_grad);

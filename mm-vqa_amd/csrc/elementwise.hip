@@ -1417,6 +1417,201 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
   }
 }
 
+// ---- image-tiled forms of the three depthwise kernels (round 2).  The pixel-strided forms above evaluate
+// silu(bn(z1)) (forward, weight gradient) and P*g + Q*z2 + R (both gradients) once per TAP: nine transcendental
+// evaluations per element.  Here a workgroup owns one image x 32 channels, stages the activated input (or dz2) of the
+// WHOLE map in LDS once (14x14x32 floats = 25 KB; 28x28 = 100 KB) and takes the nine taps from there.  Used whenever the
+// map fits (every depthwise layer of tf_efficientnetv2_m at 224x224: 28x28 -> 14x14, 14x14, 14x14 -> 7x7, 7x7).
+#define DW_TILE_MAX_BYTES (150 * 1024)
+__device__ __forceinline__ void dw_reduce_stats(double* red, const double (&sa)[4], const double (&sb)[4],
+                                                double* __restrict__ stat, int C, int cbase, int slot) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[threadIdx.x * 8 + j] = sa[j]; red[threadIdx.x * 8 + 4 + j] = sb[j]; }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int qq = threadIdx.x >> 2, j = threadIdx.x & 3;
+    double a0 = 0, a1 = 0;
+    for (int r = 0; r < 32; ++r) { a0 += red[(r * 8 + qq) * 8 + j]; a1 += red[(r * 8 + qq) * 8 + 4 + j]; }
+    double* d = stat + ((size_t)slot * C + cbase + qq * 4 + j) * 2;
+    atomicAdd(d, a0);
+    atomicAdd(d + 1, a1);
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv_fwd_tile_kernel(const float* __restrict__ z1, const float* __restrict__ s1,
+                                                             const float* __restrict__ b1, const float* __restrict__ w,
+                                                             float* __restrict__ z2, double* __restrict__ stat, int H,
+                                                             int W, int C, int OH, int OW, int stride, int pad) {
+  extern __shared__ __attribute__((aligned(16))) float dwsm[];
+  f32x4* act = reinterpret_cast<f32x4*>(dwsm);                              // [H*W][8]
+  double* red = reinterpret_cast<double*>(dwsm + (size_t)H * W * 32);       // [256][8]
+  const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int n = blockIdx.y, cb = blockIdx.x * 32, c = cb + q * 4;
+  const f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
+  f32x4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[t][j] = w[(size_t)(c + j) * 9 + t];
+  const float* zin = z1 + (size_t)n * H * W * C + c;
+  for (int p = pl; p < H * W; p += 32) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(zin + (size_t)p * C);
+    f32x4 a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = silu_f(v[j] * sv[j] + bv[j]);
+    act[p * 8 + q] = a;
+  }
+  __syncthreads();
+  double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+  float* zout = z2 + (size_t)n * OH * OW * C + c;
+  for (int op = pl; op < OH * OW; op += 32) {
+    const int oy = op / OW, ox = op - oy * OW;
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int y = oy * stride - pad + kh;
+      if (y < 0 || y >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int x = ox * stride - pad + kw;
+        if (x < 0 || x >= W) continue;
+        const f32x4 a = act[(y * W + x) * 8 + q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += a[j] * wv[kh * 3 + kw][j];
+      }
+    }
+    *reinterpret_cast<f32x4*>(zout + (size_t)op * C) = acc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sa[j] += (double)acc[j]; sb[j] += (double)acc[j] * (double)acc[j]; }
+  }
+  if (stat) dw_reduce_stats(red, sa, sb, stat, C, cb, n & (MMVQA_STAT_SLOTS - 1));
+}
+
+__global__ __launch_bounds__(256) void dwconv_bwd_data_tile_kernel(
+    const float* __restrict__ g2, const float* __restrict__ z2, const float* __restrict__ P, const float* __restrict__ Q,
+    const float* __restrict__ R, const float* __restrict__ w, const float* __restrict__ z1, const float* __restrict__ s1,
+    const float* __restrict__ b1, const float* __restrict__ mean1, const float* __restrict__ invstd1,
+    float* __restrict__ g1, double* __restrict__ stat, int H, int W, int C, int OH, int OW, int stride, int pad) {
+  extern __shared__ __attribute__((aligned(16))) float dwsm[];
+  f32x4* dzs = reinterpret_cast<f32x4*>(dwsm);                              // [OH*OW][8]  dz2 = P*g2 + Q*z2 + R
+  double* red = reinterpret_cast<double*>(dwsm + (size_t)OH * OW * 32);
+  const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int n = blockIdx.y, cb = blockIdx.x * 32, c = cb + q * 4;
+  const f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean1 + c), is = *reinterpret_cast<const f32x4*>(invstd1 + c);
+  const f32x4 Pv = *reinterpret_cast<const f32x4*>(P + c), Qv = *reinterpret_cast<const f32x4*>(Q + c),
+              Rv = *reinterpret_cast<const f32x4*>(R + c);
+  f32x4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[t][j] = w[(size_t)(c + j) * 9 + t];
+  const size_t ob = (size_t)n * OH * OW * C + c;
+  for (int op = pl; op < OH * OW; op += 32) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g2 + ob + (size_t)op * C), zv = *reinterpret_cast<const f32x4*>(z2 + ob + (size_t)op * C);
+    f32x4 d;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = gv[j] * Pv[j] + zv[j] * Qv[j] + Rv[j];
+    dzs[op * 8 + q] = d;
+  }
+  __syncthreads();
+  double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+  const size_t ib = (size_t)n * H * W * C + c;
+  for (int p = pl; p < H * W; p += 32) {
+    const int y = p / W, x = p - y * W;
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ty = y + pad - kh;
+      if (ty < 0 || ty % stride) continue;
+      const int oy = ty / stride;
+      if (oy >= OH) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tx = x + pad - kw;
+        if (tx < 0 || tx % stride) continue;
+        const int ox = tx / stride;
+        if (ox >= OW) continue;
+        const f32x4 d = dzs[(oy * OW + ox) * 8 + q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += d[j] * wv[kh * 3 + kw][j];
+      }
+    }
+    const f32x4 z = *reinterpret_cast<const f32x4*>(z1 + ib + (size_t)p * C);
+    f32x4 o4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o4[j] = acc[j] * dsilu_f(z[j] * sv[j] + bv[j]);
+      sa[j] += (double)o4[j];
+      sb[j] += (double)(o4[j] * ((z[j] - mu[j]) * is[j]));
+    }
+    *reinterpret_cast<f32x4*>(g1 + ib + (size_t)p * C) = o4;
+  }
+  dw_reduce_stats(red, sa, sb, stat, C, cb, n & (MMVQA_STAT_SLOTS - 1));
+}
+
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_tile_kernel(
+    const float* __restrict__ g2, const float* __restrict__ z2, const float* __restrict__ P, const float* __restrict__ Q,
+    const float* __restrict__ R, const float* __restrict__ z1, const float* __restrict__ s1, const float* __restrict__ b1,
+    float* __restrict__ dw, int H, int W, int C, int OH, int OW, int stride, int pad) {
+  extern __shared__ __attribute__((aligned(16))) float dwsm[];
+  f32x4* act = reinterpret_cast<f32x4*>(dwsm);                              // [H*W][8]
+  f32x4* dzs = act + (size_t)H * W * 8;                                     // [OH*OW][8]
+  float* red = dwsm + ((size_t)H * W + (size_t)OH * OW) * 32;               // [32*8][36]
+  const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int n = blockIdx.y, cb = blockIdx.x * 32, c = cb + q * 4;
+  const f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
+  const f32x4 Pv = *reinterpret_cast<const f32x4*>(P + c), Qv = *reinterpret_cast<const f32x4*>(Q + c),
+              Rv = *reinterpret_cast<const f32x4*>(R + c);
+  const size_t ib = (size_t)n * H * W * C + c, ob = (size_t)n * OH * OW * C + c;
+  for (int p = pl; p < H * W; p += 32) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(z1 + ib + (size_t)p * C);
+    f32x4 a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = silu_f(v[j] * sv[j] + bv[j]);
+    act[p * 8 + q] = a;
+  }
+  for (int op = pl; op < OH * OW; op += 32) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g2 + ob + (size_t)op * C), zv = *reinterpret_cast<const f32x4*>(z2 + ob + (size_t)op * C);
+    f32x4 d;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = gv[j] * Pv[j] + zv[j] * Qv[j] + Rv[j];
+    dzs[op * 8 + q] = d;
+  }
+  __syncthreads();
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0, 0, 0, 0};
+  for (int op = pl; op < OH * OW; op += 32) {
+    const int oy = op / OW, ox = op - oy * OW;
+    const f32x4 dz = dzs[op * 8 + q];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int y = oy * stride - pad + kh;
+      if (y < 0 || y >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int x = ox * stride - pad + kw;
+        if (x < 0 || x >= W) continue;
+        const f32x4 a = act[(y * W + x) * 8 + q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[kh * 3 + kw][j] += dz[j] * a[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(pl * 8 + q) * 36 + j * 9 + t] = acc[t][j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * 36; i += 256) {   // (quad, channel-in-quad * 9 + tap)
+    const int qq = i / 36, e = i - qq * 36;
+    float a0 = 0.f;
+    for (int r = 0; r < 32; ++r) a0 += red[(r * 8 + qq) * 36 + e];
+    atomicAdd(&dw[(size_t)(cb + qq * 4) * 9 + e], a0);
+  }
+}
+
 // squeeze: pool[n][c] = mean_hw silu(z*s+b)
 // Workgroup = 16 channel quads (64 channels) x 16 pixel lanes of ONE image: every pixel row of the chunk is a
 // 256-byte segment, the HW pixels are spread over the 16 lanes and reduced through LDS (one thread per image and
@@ -1549,9 +1744,23 @@ int k_bn_act_add(hipStream_t st, const float* z, const float* s, const float* b,
   return MMVQA_OK;
 }
 
+static bool dw_pixel_form() {   // A/B switch: the pixel-strided kernels even where a map fits in LDS
+  static const bool v = getenv("MMVQA_DW_PIXEL") != nullptr;
+  return v;
+}
+
 int k_dwconv_fwd(hipStream_t st, const float* z1, const float* s1, const float* b1, const float* w, float* z2,
                  double* stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad) {
   if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
+  const size_t sm = (size_t)H * W * 128 + 256 * 8 * sizeof(double);
+  if (sm <= DW_TILE_MAX_BYTES && !dw_pixel_form()) {
+    static bool attr = false;
+    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_fwd_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES)); attr = true; }
+    hipLaunchKernelGGL(dwconv_fwd_tile_kernel, dim3(C / 32, N), dim3(256), sm, st, z1, s1, b1, w, z2, stat, H, W, C, OH, OW,
+                       stride, pad);
+    KERNEL_CHECK_RET();
+    return MMVQA_OK;
+  }
   hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(pix_grid((long)N * OH * OW, C / 32), C / 32), dim3(256), 0, st, z1, s1, b1,
                      w, z2, stat, N, H, W, C, OH, OW, stride, pad);
   KERNEL_CHECK_RET();
@@ -1563,6 +1772,15 @@ int k_dwconv_bwd_data(hipStream_t st, const float* g2, const float* z2, const fl
                       const float* mean1, const float* invstd1, float* g1, double* stat, int N, int H, int W, int C,
                       int OH, int OW, int stride, int pad) {
   if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
+  const size_t sm = (size_t)OH * OW * 128 + 256 * 8 * sizeof(double);
+  if (sm <= DW_TILE_MAX_BYTES && !dw_pixel_form()) {
+    static bool attr = false;
+    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_bwd_data_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES)); attr = true; }
+    hipLaunchKernelGGL(dwconv_bwd_data_tile_kernel, dim3(C / 32, N), dim3(256), sm, st, g2, z2, P, Q, R, w, z1, s1, b1,
+                       mean1, invstd1, g1, stat, H, W, C, OH, OW, stride, pad);
+    KERNEL_CHECK_RET();
+    return MMVQA_OK;
+  }
   hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(pix_grid((long)N * H * W, C / 32), C / 32), dim3(256), 0, st, g2, z2,
                      P, Q, R, w, z1, s1, b1, mean1, invstd1, g1, stat, N, H, W, C, OH, OW, stride, pad);
   KERNEL_CHECK_RET();
@@ -1573,6 +1791,15 @@ int k_dwconv_bwd_weight(hipStream_t st, const float* g2, const float* z2, const 
                         const float* R, const float* z1, const float* s1, const float* b1, float* dw, int N, int H,
                         int W, int C, int OH, int OW, int stride, int pad) {
   if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
+  const size_t sm = ((size_t)H * W + (size_t)OH * OW) * 128 + 32 * 8 * 36 * sizeof(float);
+  if (sm <= DW_TILE_MAX_BYTES && !dw_pixel_form()) {
+    static bool attr = false;
+    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_bwd_weight_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES)); attr = true; }
+    hipLaunchKernelGGL(dwconv_bwd_weight_tile_kernel, dim3(C / 32, N), dim3(256), sm, st, g2, z2, P, Q, R, z1, s1, b1, dw, H, W,
+                       C, OH, OW, stride, pad);
+    KERNEL_CHECK_RET();
+    return MMVQA_OK;
+  }
   int g = pix_grid((long)N * OH * OW, C / 32);
   if (g > 64) g = 64;   // every workgroup ends with 288 atomics per 32 channels
   hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(g, C / 32), dim3(256), 0, st, g2, z2, P, Q, R, z1, s1, b1, dw, N,

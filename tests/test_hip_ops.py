@@ -651,3 +651,104 @@ def test_meanpool_l2norm():
     torch.cuda.synchronize()
     assert_close(y, y_ref, TOL, "l2norm")
     assert_close(dx, x.grad, TOL, "l2norm bwd")
+
+
+# ----------------------------------------------------------------------------- EfficientNetV2 pieces (timm MBConv)
+def _same_pad(size, k, s):
+    out = math.ceil(size / s)
+    total = max((out - 1) * s + k - size, 0)
+    return total // 2, total - total // 2
+
+
+@pytest.mark.parametrize("N,H,W,Cc,stride", [(2, 14, 14, 64, 1), (3, 7, 7, 96, 1), (2, 14, 14, 32, 2), (2, 28, 28, 64, 2),
+                                           (1, 40, 36, 32, 1), (2, 9, 11, 64, 2)])
+def test_dwconv_fwd_bwd(N, H, W, Cc, stride):
+    """depthwise 3x3 with TF-SAME padding, BN+SiLU applied on load, statistics, data and weight gradients
+    (image-tiled kernels where the map fits in LDS, pixel-strided ones for 40x36) vs torch conv2d(groups=C)"""
+    torch.manual_seed(20)
+    z1 = torch.randn(N, Cc, H, W)
+    sc, sh = torch.rand(Cc) + 0.5, torch.randn(Cc) * 0.3
+    w = (torch.randn(Cc, 1, 3, 3) / 3).requires_grad_(True)
+    pt, pb = _same_pad(H, 3, stride)
+    pl, pr = _same_pad(W, 3, stride)
+    zin = z1.clone().requires_grad_(True)
+    a = F.silu(zin * sc[None, :, None, None] + sh[None, :, None, None])
+    z2 = F.conv2d(F.pad(a, (pl, pr, pt, pb)), w, stride=stride, groups=Cc)
+    OH, OW = z2.shape[2:]
+    z1d, wd = nhwc(z1), w.detach().reshape(Cc, 9).contiguous().to(dev())
+    scd, shd = sc.to(dev()), sh.to(dev())
+    out = torch.zeros(N * OH * OW, Cc, device=dev())
+    stat = torch.zeros(L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=dev())
+    L.check(L.lib().mmvqa_dwconv_fwd(L.stream_ptr(), P(z1d), P(scd), P(shd), P(wd), P(out), P(stat), N, H, W, Cc, OH, OW, stride, pt))
+    torch.cuda.synchronize()
+    assert pt == pl
+    assert_close(from_nhwc(out, N, OH, OW, Cc), z2, TOL, "dwconv fwd")
+    st = stat.sum(0).cpu()
+    assert_close(st[:, 0], z2.sum(dim=(0, 2, 3)).double(), 1e-5, "sum")
+    assert_close(st[:, 1], (z2.double() ** 2).sum(dim=(0, 2, 3)), 1e-5, "sumsq")
+    # backward through dz2 = Pc*g2 + Qc*z2 + Rc
+    g2 = torch.randn_like(z2)
+    Pc, Qc, Rc = torch.rand(Cc) + 0.5, torch.randn(Cc) * 0.1, torch.randn(Cc) * 0.1
+    dz2 = g2 * Pc[None, :, None, None] + z2.detach() * Qc[None, :, None, None] + Rc[None, :, None, None]
+    z2.backward(dz2)
+    mu, istd = torch.randn(Cc) * 0.1, torch.rand(Cc) + 0.5
+    g2d = nhwc(g2)
+    coef = [t.to(dev()) for t in (Pc, Qc, Rc, mu, istd)]
+    g1 = torch.zeros(N * H * W, Cc, device=dev())
+    bst = torch.zeros(L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=dev())
+    L.check(L.lib().mmvqa_dwconv_bwd_data(L.stream_ptr(), P(g2d), P(out), P(coef[0]), P(coef[1]), P(coef[2]), P(wd), P(z1d), P(scd),
+                                          P(shd), P(coef[3]), P(coef[4]), P(g1), P(bst), N, H, W, Cc, OH, OW, stride, pt))
+    torch.cuda.synchronize()
+    # zin.grad = dL/dz1 = da * silu'(.) * sc ; the kernel returns du = da * silu'(.) (the BN scale is applied by the next stage)
+    du_ref = zin.grad / sc[None, :, None, None]
+    assert_close(from_nhwc(g1, N, H, W, Cc), du_ref, TOL, "dwconv bwd data")
+    xhat = (z1 - mu[None, :, None, None]) * istd[None, :, None, None]
+    bs = bst.sum(0).cpu()
+    assert_close(bs[:, 0], du_ref.sum(dim=(0, 2, 3)).double(), 1e-4, "sum du")
+    assert_close(bs[:, 1], (du_ref * xhat).sum(dim=(0, 2, 3)).double(), 1e-4, "sum du xhat")
+    dw = torch.zeros(Cc, 9, device=dev())
+    L.check(L.lib().mmvqa_dwconv_bwd_weight(L.stream_ptr(), P(g2d), P(out), P(coef[0]), P(coef[1]), P(coef[2]), P(z1d), P(scd), P(shd),
+                                            P(dw), N, H, W, Cc, OH, OW, stride, pt))
+    torch.cuda.synchronize()
+    assert_close(dw.view(Cc, 1, 3, 3), w.grad, TOL, "dwconv bwd weight")
+
+
+def test_squeeze_excite_and_block_end_kernels():
+    """se_pool / se_dgate / act_bwd_stats / bn_act_add vs plain torch (C not a multiple of 64, HW not a multiple of 16)"""
+    torch.manual_seed(21)
+    N, HW, Cc = 3, 49, 88
+    z, t = torch.randn(N, HW, Cc), torch.randn(N, HW, Cc)
+    sc, sh = torch.rand(Cc) + 0.5, torch.randn(Cc) * 0.3
+    a = F.silu(z * sc + sh)
+    zd, td, scd, shd = (x.contiguous().to(dev()) for x in (z, t, sc, sh))
+    pool, dgate = torch.zeros(N, Cc, device=dev()), torch.zeros(N, Cc, device=dev())
+    L.check(L.lib().mmvqa_se_pool(L.stream_ptr(), P(zd), P(scd), P(shd), P(pool), N, HW, Cc))
+    L.check(L.lib().mmvqa_se_dgate(L.stream_ptr(), P(td), P(zd), P(scd), P(shd), P(dgate), N, HW, Cc))
+    torch.cuda.synchronize()
+    assert_close(pool, a.mean(1), TOL, "se_pool")
+    assert_close(dgate, (t * a).sum(1), TOL, "se_dgate")
+    # du = (t * gate + add / HW) * silu'(z*sc+sh); sums of du and du*xhat
+    gate, add = torch.rand(N, Cc), torch.randn(N, Cc)
+    mu, istd = torch.randn(Cc) * 0.1, torch.rand(Cc) + 0.5
+    u = (z * sc + sh).requires_grad_(True)
+    F.silu(u).backward(t * gate[:, None, :] + add[:, None, :] / HW)
+    out = torch.zeros(N * HW, Cc, device=dev())
+    stat = torch.zeros(L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=dev())
+    gd, ad, mud, isd = (x.contiguous().to(dev()) for x in (gate, add, mu, istd))
+    L.check(L.lib().mmvqa_act_bwd_stats(L.stream_ptr(), P(td), P(gd), P(ad), P(zd), P(scd), P(shd), P(mud), P(isd), L.ACT_SILU,
+                                        P(out), P(stat), N * HW, HW, Cc))
+    torch.cuda.synchronize()
+    assert_close(out.view(N, HW, Cc), u.grad, TOL, "act_bwd_stats")
+    st = stat.sum(0).cpu()
+    assert_close(st[:, 0], u.grad.sum((0, 1)).double(), 1e-4, "sum du")
+    assert_close(st[:, 1], (u.grad * ((z - mu) * istd)).sum((0, 1)).double(), 1e-4, "sum du xhat")
+    # block end: out = act(z*sc+sh) + skip   and   out = (z*sc+sh) + skip
+    idn = torch.randn(N * HW, Cc)
+    idd = idn.to(dev())
+    o = torch.zeros(N * HW, Cc, device=dev())
+    L.check(L.lib().mmvqa_bn_act_add(L.stream_ptr(), P(zd), P(scd), P(shd), L.ACT_SILU, P(idd), None, None, 0, 0, P(o), N * HW, Cc))
+    torch.cuda.synchronize()
+    assert_close(o, a.view(-1, Cc) + idn, TOL, "bn_act_add silu + skip")
+    L.check(L.lib().mmvqa_bn_act_add(L.stream_ptr(), P(zd), P(scd), P(shd), L.ACT_NONE, None, None, None, 0, 0, P(o), N * HW, Cc))
+    torch.cuda.synchronize()
+    assert_close(o, (z * sc + sh).view(-1, Cc), TOL, "bn_act_add plain")
