@@ -1341,6 +1341,9 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
     }
   }
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splitk);
+  if (getenv("MMVQA_IGEMM_LOG"))   // one line per launch: which loader family a shape gets (diagnostics)
+    fprintf(stderr, "igemm kind %d fast %d tile %dx%dx%d ks %d M %d N %d K %d Cs %d taps %d stride %d apro %d bpro %d splitk %d\n", KIND, x.fast,
+            BM, BN, BK, KS, p.M, p.N, p.K, p.g_Cs, p.g_KH * p.g_KW, p.g_stride, p.a_pro, p.b_pro, p.splitk);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, KIND, NCHW, KS>), grid, dim3(256 * KS), smem, stream, p, x);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
