@@ -1444,6 +1444,7 @@ int engine_create(const mmvqa_model_desc* desc, mmvqa_engine** out) {
     return mmvqa_set_error(MMVQA_ERR_ARG, "engine_create: resnet_width=%d must be a multiple of 8", d.resnet_width);
   mmvqa_engine* e = new mmvqa_engine();
   e->d = d;
+  if (getenv("MMVQA_NO_SIDE_STREAM")) e->use_side = 0;   // A/B switch: everything on the caller's stream
   memset(e->prof_launch, 0, sizeof(e->prof_launch));
   memset(e->prof_ms, 0, sizeof(e->prof_ms));
   memset(e->prof_flops, 0, sizeof(e->prof_flops));
