@@ -171,11 +171,19 @@ def main():
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: one process per GPU -- launch with "
                  f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 "
                  f"bench.py --gpus {a.gpus} ...`")
+    # rehearsal of the N>1 path on a ONE-GPU box (not a measurement): MMVQA_REHEARSE_GLOO=1 puts every rank on cuda:0
+    # and exchanges over gloo; the driver's runs use one GPU per rank over RCCL ("nccl")
+    rehearse = bool(os.environ.get("MMVQA_REHEARSE_GLOO"))
+    if rehearse:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
 
