@@ -175,13 +175,6 @@ def test_full_config2_resnet152_224():
              kind="mlm", stat_tol=TOL)
 
 
-def test_full_config3_effnetv2m_realformer_224():
-    """BASELINE.json configs[2]: tf_efficientnetv2_m at full depth (57 blocks) + RealFormer, 224x224, batch 2"""
-    run_case(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer", heads=8,
-                         hidden_dropout_prob=0.0, emb_dropout_prob=0.0, rf_dropout_prob=0.0), B=2, T=32, hw=224,
-             kind="mlm", stat_tol=TOL)
-
-
 def test_full_config2_batch16_the_bench_shape():
     """configs[1] exactly as bench.py runs it: per-GPU batch 16 (the tile / split-K choices and the grids differ from
     the batch-2 case above)"""
@@ -189,21 +182,24 @@ def test_full_config2_batch16_the_bench_shape():
              kind="mlm", stat_tol=TOL)
 
 
-def test_full_config4_effnetv2m_realformer_supcon_224():
-    """BASELINE.json configs[3]: pretrain/roco_supcon_train.py, tf_efficientnetv2_m at full depth + RealFormer, MLM head
-    + SupCon head on 2N views (two crops per sample concatenated along the batch), 224x224, T 32, vocab 30522 --
-    logits, feat, MLM + SupCon loss, every gradient, BatchNorm buffers (2N = 4 keeps the fp32 + fp64 CPU oracle in seconds)"""
+def test_full_config3_and_4_effnetv2m_realformer_mlm_supcon_224():
+    """BASELINE.json configs[2] AND configs[3]: tf_efficientnetv2_m at full depth (57 blocks) + RealFormer, 224x224, T 32,
+    vocab 30522 -- configs[2] is pretrain/roco_train.py (MLM head), configs[3] is pretrain/roco_supcon_train.py, the same
+    model with the SupCon head added on 2N views (two crops per sample concatenated along the batch): one run checks
+    the MLM logits and loss of both, feat, the SupCon loss, every gradient and the BatchNorm buffers against the fp32 /
+    fp64 oracle (2N = 4 keeps the CPU oracle to about a minute and a half)"""
     run_case(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer", heads=8, supcon=True,
                          hidden_dropout_prob=0.0, emb_dropout_prob=0.0, rf_dropout_prob=0.0), B=4, T=32, hw=224,
              kind="supcon", stat_tol=TOL)
 
 
-def test_full_config5_effnetv2m_realformer_vqa_asl_224():
+def test_full_config5_effnetv2m_realformer_vqa_asl():
     """BASELINE.json configs[4]: vqamed2019/train.py --loss=ASLSingleLabel, tf_efficientnetv2_m + RealFormer, VQA head
-    (masked mean-pool) with 1552 answer classes, 224x224, T 28 (the script's default), batch 2"""
+    (masked mean-pool) with 1552 answer classes, T 28 (the script's default), full depth and width, batch 2; 160x160
+    images (the 224x224 backbone is the test above; this one is about the VQA head, ASL and T = 28 at full width)"""
     run_case(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer", heads=8, dataset="VQA-Med",
                          vocab_size=1552, emb_vocab=30522, hidden_dropout_prob=0.0, emb_dropout_prob=0.0,
-                         rf_dropout_prob=0.0), B=2, T=28, hw=224, kind="vqa", stat_tol=TOL)
+                         rf_dropout_prob=0.0), B=2, T=28, hw=160, kind="vqa", stat_tol=TOL)
 
 
 @pytest.mark.parametrize("tag,tm,ds,supcon,cnn,relu", MODEL_CASES)
