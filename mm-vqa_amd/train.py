@@ -69,10 +69,17 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        rehearse = bool(os.environ.get("MMVQA_REHEARSE_GLOO"))   # every rank on cuda:0 over gloo: one-GPU rehearsal only
+        if rehearse:
+            local = 0
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            if rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         self.dev = torch.device("cuda", local if self.world > 1 else 0)
         torch.cuda.set_device(self.dev)
 
