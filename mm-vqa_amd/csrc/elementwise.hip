@@ -554,7 +554,7 @@ __global__ void lsm_nll_kernel(const float* __restrict__ logits, int ld, const l
 // One 1024-thread workgroup per row (2 rows per CU in flight = full wave occupancy), ONE pass over the row with
 // float4 loads, LSM_U of them in flight per thread; a thread keeps a running (max, first index, sum) and rescales
 // its sum once per chunk, not per element.  Algorithmic bytes: rows * V * 4 read once (62.5 MB at B*T=512, V=30522).
-#define LSM_U 8
+#define LSM_U 4
 __device__ __forceinline__ void lsm_combine(float& m, int& mi, float& s, float om, int oi, float os) {
   const float M = fmaxf(m, om);
   const float sa = (m == -INFINITY) ? 0.f : s * expf(m - M);
