@@ -194,7 +194,6 @@ void mmvqa_engine_destroy(mmvqa_engine* e) {
   if (!e) return;
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->side) (void)hipStreamDestroy(e->side);
-  for (auto& kv : e->pixmasks) (void)hipFree(kv.second);
   delete e;
 }
 int mmvqa_engine_num_tensors(const mmvqa_engine* e) { return e ? (int)e->specs.size() : 0; }
@@ -231,6 +230,7 @@ int mmvqa_engine_bind(mmvqa_engine* e, float* params, float* grads, float* bufs,
     return mmvqa_set_error(MMVQA_ERR_ARG, "bind: buffers must be 16-byte aligned");
   e->params = params; e->grads = grads; e->bufs = bufs; e->nbt = nbt;
   e->ws = reinterpret_cast<float*>(workspace);
+  e->pixmask_built.clear();   // tables live in the (new) workspace: rebuilt on first use
   e->bound = true;
   e->img = nullptr;
   return MMVQA_OK;

@@ -266,6 +266,7 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
     return 0;
   }
   e->B = B; e->T = T; e->IH = IH; e->IW = IW;
+  e->pixmask_off.clear(); e->pixmask_built.clear();
   Arena a;
   const int H = d.hidden;
   const size_t M = (size_t)B * T;
@@ -339,6 +340,11 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
     blk.OH = conv_out(h, 3, blk.c2.stride, 1); blk.OW = conv_out(wd, 3, blk.c2.stride, 1);
     const size_t Min = (size_t)B * h * wd, Mout = (size_t)B * blk.OH * blk.OW;
     blk.z1 = a.f(Min * blk.c1.Cout);
+    if (blk.c2.stride == 1) {   // per-pixel tap-validity table of the 3x3 weight gradient: one per geometry, in the workspace
+      char key[96];
+      snprintf(key, sizeof(key), "%d,%d,%d,%d,%d", B, blk.OH, blk.OW, blk.c2.KH, blk.c2.pad);
+      if (!e->pixmask_off.count(key)) e->pixmask_off[key] = a.f(Mout);
+    }
     blk.z2 = a.f(Mout * blk.c2.Cout);
     blk.z3 = a.f(Mout * blk.c3.Cout);
     blk.out = a.f(Mout * blk.c3.Cout);
@@ -608,14 +614,15 @@ static int conv_wgrad(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const f
     // stride-1 "same" convolution: hand the kernel the per-pixel tap-validity table (one per geometry)
     char key[96];
     snprintf(key, sizeof(key), "%d,%d,%d,%d,%d", N, OH, OW, c.KH, c.pad);
-    auto it = e->pixmasks.find(key);
-    if (it == e->pixmasks.end()) {
-      int* tab = nullptr;
-      HIP_CHECK_RET(hipMalloc(&tab, sizeof(int) * (size_t)N * OH * OW));
-      it = e->pixmasks.emplace(key, tab).first;
-      TRY(k_pixmask(st, tab, N, OH, OW, H, W, c.KH, c.KH, c.stride, c.pad));
+    auto it = e->pixmask_off.find(key);
+    if (it != e->pixmask_off.end()) {
+      int* tab = reinterpret_cast<int*>(WS(it->second));
+      if (!e->pixmask_built[key]) {
+        TRY(k_pixmask(st, tab, N, OH, OW, H, W, c.KH, c.KH, c.stride, c.pad));
+        e->pixmask_built[key] = true;
+      }
+      g.pixmask = tab;
     }
-    g.pixmask = it->second;
   }
   RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_WGRAD, 0, 0, st));
   return MMVQA_OK;

@@ -141,7 +141,8 @@ struct mmvqa_engine {
   size_t ev_next = 0;
   int use_side = 1;
   // ---- per-geometry tap-validity tables of the 3x3 weight gradients (mmvqa_gemm_desc.pixmask), built on first use
-  std::map<std::string, int*> pixmasks;
+  std::map<std::string, size_t> pixmask_off;   // workspace offset per geometry (planned)
+  std::map<std::string, bool> pixmask_built;   // filled on first use after every bind (the workspace is the caller's)
   // ---- gradient-ready notifications (data-parallel overlap): called on the host right after the kernels that
   // complete grads[lo, hi) have been enqueued and the main stream has been ordered behind them
   void (*grad_cb)(void* user, long long lo, long long hi) = nullptr;
