@@ -14,6 +14,7 @@ The forward pass is the HIP engine (mmvqa_amd.Model); the metrics are host bookk
 from __future__ import annotations
 
 import math
+import warnings
 from collections import Counter
 
 import numpy as np
@@ -57,8 +58,8 @@ def category_metrics(preds, targets, categories, idx2ans, prefix=""):
     for c in CATEGORIES:
         sel = cats == c
         short = _SHORT.get(c, c)
-        with np.errstate(invalid="ignore"), __import__("warnings").catch_warnings():
-            __import__("warnings").simplefilter("ignore")
+        with np.errstate(invalid="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore")          # an empty category gives nan ("Mean of empty slice"), as upstream
             acc[prefix + short + "_acc"] = np.round((preds[sel] == targets[sel]).mean() * 100., 4)
             bleu[prefix + short + "_bleu"] = np.round(calculate_bleu_score(preds[sel], targets[sel], idx2ans), 4)
     return acc, bleu
