@@ -235,6 +235,17 @@ int mmvqa_dwconv_bwd_weight(mmvqa_stream_t s, const float* g2, const float* z2, 
 int mmvqa_se_pool(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, float* pool, int N, int HW, int C);
 int mmvqa_se_dgate(mmvqa_stream_t s, const float* t, const float* z, const float* sc, const float* sh, float* dgate,
                    int N, int HW, int C);
+/* squeeze-excite fully connected layers (timm SqueezeExcite conv_reduce / conv_expand on the pooled [B, mid] tensor):
+ *   rpre = pool Wr^T + br, r = silu(rpre)   [B, rd]   Wr [rd, mid]
+ *   gpre = r We^T + be,    gate = sigmoid(gpre) [B, mid]   We [mid, rd]
+ * backward: from dgate [B, mid] accumulates dWe, dbe, dWr, dbr (+=) and writes dpool [B, mid]; `scratch` holds
+ * mmvqa_se_fc_bwd_scratch_floats(B, mid, rd) floats; rd <= 128. */
+int mmvqa_se_fc_fwd(mmvqa_stream_t s, const float* pool, const float* Wr, const float* br, const float* We,
+                    const float* be, float* rpre, float* r, float* gpre, float* gate, int B, int mid, int rd);
+size_t mmvqa_se_fc_bwd_scratch_floats(int B, int mid, int rd);
+int mmvqa_se_fc_bwd(mmvqa_stream_t s, const float* dgate, const float* gpre, const float* r, const float* rpre,
+                    const float* pool, const float* We, const float* Wr, float* dWe, float* dbe, float* dWr, float* dbr,
+                    float* dpool, float* scratch, int B, int mid, int rd);
 /* out = (t * gate[n][c] + add[n][c] / HW) * act'(z*sc+sh) (gate/add nullable); BatchNorm-backward sums into stat */
 int mmvqa_act_bwd_stats(mmvqa_stream_t s, const float* t, const float* gate, const float* add, const float* z,
                         const float* sc, const float* sh, const float* mean, const float* invstd, int act, float* out,

@@ -111,6 +111,9 @@ SIGNATURES = {
     "mmvqa_dwconv_bwd_weight": (_i, [_P] * 10 + [_i] * 8),
     "mmvqa_se_pool": (_i, [_P, _P, _P, _P, _P, _i, _i, _i]),
     "mmvqa_se_dgate": (_i, [_P, _P, _P, _P, _P, _P, _i, _i, _i]),
+    "mmvqa_se_fc_fwd": (_i, [_P] * 10 + [_i, _i, _i]),
+    "mmvqa_se_fc_bwd_scratch_floats": (_sz, [_i, _i, _i]),
+    "mmvqa_se_fc_bwd": (_i, [_P] * 14 + [_i, _i, _i]),
     "mmvqa_act_bwd_stats": (_i, [_P] * 9 + [_i, _P, _P, _l, _i, _i]),
     "mmvqa_bn_act_add": (_i, [_P, _P, _P, _P, _i, _P, _P, _P, _i, _i, _P, _l, _i]),
     "mmvqa_adam": (_i, [_P, _P, _P, _P, _P, _l, _d, _d, _d, _d, _i, _f, _i]),

@@ -161,6 +161,18 @@ int mmvqa_se_dgate(mmvqa_stream_t s, const float* t, const float* z, const float
                    int N, int HW, int C) {
   return k_se_dgate(ST(s), t, z, sc, sh, dgate, N, HW, C);
 }
+int mmvqa_se_fc_fwd(mmvqa_stream_t s, const float* pool, const float* Wr, const float* br, const float* We,
+                    const float* be, float* rpre, float* r, float* gpre, float* gate, int B, int mid, int rd) {
+  int rc = k_skinny_fwd(ST(s), pool, mid, Wr, br, ACT_SILU, rpre, r, B, rd, mid);
+  if (rc != MMVQA_OK) return rc;
+  return k_skinny_fwd(ST(s), r, rd, We, be, ACT_SIGMOID, gpre, gate, B, mid, rd);
+}
+size_t mmvqa_se_fc_bwd_scratch_floats(int B, int mid, int rd) { return k_se_fc_bwd_scratch_floats(B, mid, rd); }
+int mmvqa_se_fc_bwd(mmvqa_stream_t s, const float* dgate, const float* gpre, const float* r, const float* rpre,
+                    const float* pool, const float* We, const float* Wr, float* dWe, float* dbe, float* dWr, float* dbr,
+                    float* dpool, float* scratch, int B, int mid, int rd) {
+  return k_se_fc_bwd(ST(s), dgate, gpre, r, rpre, pool, We, Wr, dWe, dbe, dWr, dbr, dpool, scratch, 0, B, mid, rd);
+}
 int mmvqa_act_bwd_stats(mmvqa_stream_t s, const float* t, const float* gate, const float* add, const float* z,
                         const float* sc, const float* sh, const float* mean, const float* invstd, int act, float* out,
                         double* stat, long npix, int HW, int C) {

@@ -1645,10 +1645,13 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const float* __restrict__ 
 // dgate[n][c] = sum_hw t[pix,c] * silu(z*s+b)[pix,c]   (t = gradient wrt the gated activation); same shape
 __global__ __launch_bounds__(256) void se_dgate_kernel(const float* __restrict__ t, const float* __restrict__ z,
                                                        const float* __restrict__ s, const float* __restrict__ b,
-                                                       float* __restrict__ dgate, int HW, int C) {
+                                                       float* __restrict__ dgate, int HW, int C,
+                                                       float* __restrict__ zero, int nzero) {
   __shared__ f32x4 red[16][17];
   const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int n = blockIdx.y, c = blockIdx.x * 64 + q * 4;
+  if (zero && blockIdx.x == 0 && blockIdx.y == 0)     // clears the scratch the next kernel of the stream accumulates into
+    for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0.f;
   f32x4 acc = {0, 0, 0, 0};
   if (c < C) {
     const f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c);
@@ -1815,8 +1818,8 @@ int k_se_pool(hipStream_t st, const float* z, const float* s, const float* b, fl
 }
 
 int k_se_dgate(hipStream_t st, const float* t, const float* z, const float* s, const float* b, float* dgate, int N,
-               int HW, int C) {
-  hipLaunchKernelGGL(se_dgate_kernel, dim3(cdiv_i(C, 64), N), dim3(256), 0, st, t, z, s, b, dgate, HW, C);
+               int HW, int C, float* zero, int nzero) {
+  hipLaunchKernelGGL(se_dgate_kernel, dim3(cdiv_i(C, 64), N), dim3(256), 0, st, t, z, s, b, dgate, HW, C, zero, nzero);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }

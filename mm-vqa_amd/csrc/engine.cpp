@@ -289,7 +289,7 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
     plan_bn(a, e->stem_bn, (double)M0);
     max_io = M0 * 24;
     int h = e->SH, wd = e->SW;
-    size_t max_se = 0;
+    size_t max_se = 0, max_separt = 0;
     for (auto& blk : e->eff) {
       blk.N = B; blk.H = h; blk.W = wd;
       int p1 = same(h, 3, blk.stride, &blk.OH), p2 = same(wd, 3, blk.stride, &blk.OW);
@@ -312,6 +312,7 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
         blk.rpre = a.f((size_t)B * blk.rd); blk.r = a.f((size_t)B * blk.rd);
         max_mid = std::max(max_mid, std::max(Min, Mout) * blk.mid);
         max_se = std::max(max_se, (size_t)B * blk.mid);
+        max_separt = std::max(max_separt, k_se_fc_bwd_scratch_floats(B, blk.mid, blk.rd));
       }
       blk.out = a.f(Mout * blk.cout);
       max_io = std::max(max_io, std::max(Min * blk.cin, Mout * blk.cout));
@@ -320,6 +321,7 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
     }
     e->eff_gA = a.f(max_mid); e->eff_gB = a.f(max_mid);
     for (int i = 0; i < 6; ++i) e->eff_se[i] = a.f(max_se + 64);
+    e->eff_separt = a.f(max_separt + 64);
     for (int k = 0; k < 5; ++k) {
       max_tapM = std::max(max_tapM, (size_t)e->taps[k].M);
       e->tapgrad[k] = a.f((size_t)e->taps[k].M * e->taps[k].C);
@@ -1019,8 +1021,10 @@ static int effnet_forward(mmvqa_engine* e, hipStream_t st) {
       TRY(bn_coef_fwd(e, st, b.b_dw));
       // squeeze-excite: gate = sigmoid(W_e silu(W_r mean_hw(a2) + b_r) + b_e)
       RUN(PROF_OTHER, 0, k_se_pool(st, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift), WS(b.pool), B, b.OH * b.OW, b.mid));
-      TRY(lin_fwd(e, st, WS(b.pool), b.mid, B, b.se_r, WS(b.r), b.rd, ACT_SILU, WS(b.rpre), 0.f, 0, nullptr, 0));
-      TRY(lin_fwd(e, st, WS(b.r), b.rd, B, b.se_e, WS(b.gate), b.mid, ACT_SIGMOID, WS(b.gpre), 0.f, 0, nullptr, 0));
+      RUN(PROF_OTHER, 0, k_skinny_fwd(st, WS(b.pool), b.mid, PRM(b.se_r.w), PRM(b.se_r.b), ACT_SILU, WS(b.rpre), WS(b.r),
+                                      B, b.rd, b.mid));
+      RUN(PROF_OTHER, 0, k_skinny_fwd(st, WS(b.r), b.rd, PRM(b.se_e.w), PRM(b.se_e.b), ACT_SIGMOID, WS(b.gpre),
+                                      WS(b.gate), B, b.mid, b.rd));
       TRY(eff_conv_fwd(e, st, b.c_p, WS(b.zdw), &b.b_dw, WS(b.gate), B, b.OH, b.OW, b.OH, b.OW, WS(b.zp), b.b_p));
       RUN(PROF_OTHER, 0, k_bn_act_add(st, WS(b.zp), WS(b.b_p.scale), WS(b.b_p.shift), ACT_NONE, idn, nullptr, nullptr, 0,
                                       ACT_NONE, WS(b.out), Mout, b.cout));
@@ -1082,14 +1086,12 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
       TRY(eff_conv_wgrad(e, st, b.c_p, G, WS(b.zp), b.b_p, WS(b.zdw), &b.b_dw, WS(b.gate), B, b.OH, b.OW, b.OH, b.OW));
       TRY(conv_dgrad(e, st, b.c_p, G, WS(b.zp), b.b_p, B, b.OH, b.OW, b.OH, b.OW, gA, EpiOpt()));   // t = d(a2*gate)
       // squeeze-excite backward
-      float* dgate = WS(e->eff_se[0]); float* dgpre = WS(e->eff_se[1]); float* drpre = WS(e->eff_se[2]);
-      float* dpool = WS(e->eff_se[3]);
-      RUN(PROF_OTHER, 0, k_se_dgate(st, gA, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift), dgate, B, b.OH * b.OW, b.mid));
-      RUN(PROF_OTHER, 0, k_mul_dact(st, dgate, WS(b.gpre), ACT_SIGMOID, dgpre, (long)B * b.mid));
-      TRY(lin_wgrad(e, st, dgpre, b.mid, WS(b.r), b.rd, B, b.se_e, true));
-      TRY(lin_dgrad(e, st, dgpre, b.mid, B, b.se_e, drpre, b.rd, ACT_SILU, WS(b.rpre), b.rd, GRD(b.se_r.b), nullptr, 0));
-      TRY(lin_wgrad(e, st, drpre, b.rd, WS(b.pool), b.mid, B, b.se_r, false));
-      TRY(lin_dgrad(e, st, drpre, b.rd, B, b.se_r, dpool, b.mid, 0, nullptr, 0, nullptr, nullptr, 0));
+      float* dgate = WS(e->eff_se[0]); float* dpool = WS(e->eff_se[3]);
+      RUN(PROF_OTHER, 0, k_se_dgate(st, gA, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift), dgate, B, b.OH * b.OW, b.mid,
+                                    WS(e->eff_separt), B * b.rd));
+      RUN(PROF_OTHER, 0, k_se_fc_bwd(st, dgate, WS(b.gpre), WS(b.r), WS(b.rpre), WS(b.pool), PRM(b.se_e.w), PRM(b.se_r.w),
+                                     GRD(b.se_e.w), GRD(b.se_e.b), GRD(b.se_r.w), GRD(b.se_r.b), dpool,
+                                     WS(e->eff_separt), 1, B, b.mid, b.rd));
       // du2 = (t*gate + dpool/HW) * silu'(bn2(zdw)); BN2 sums
       RUN(PROF_OTHER, 0, k_act_bwd_stats(st, gA, WS(b.gate), dpool, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift),
                                          WS(b.b_dw.mean), WS(b.b_dw.invstd), ACT_SILU, gB, stat_ptr(e, b.b_dw.stat_b), Mout,

@@ -74,8 +74,15 @@ int k_dwconv_bwd_weight(hipStream_t st, const float* g2, const float* z2, const 
                         int W, int C, int OH, int OW, int stride, int pad);
 int k_se_pool(hipStream_t st, const float* z, const float* s, const float* b, float* pool, int N, int HW, int C);
 int k_se_dgate(hipStream_t st, const float* t, const float* z, const float* s, const float* b, float* dgate, int N,
-               int HW, int C);
+               int HW, int C, float* zero = nullptr, int nzero = 0);
 int k_act_bwd_stats(hipStream_t st, const float* t, const float* gate, const float* add, const float* z,
                     const float* s, const float* b, const float* mean, const float* invstd, int act, float* out,
                     double* stat, long npix, int HW, int C);
 int k_mul_dact(hipStream_t st, const float* x, const float* pre, int act, float* y, long n);
+// se.hip: the squeeze-excite fully connected layers (16-row problems) without the GEMM tile machinery
+int k_skinny_fwd(hipStream_t st, const float* x, int x_ld, const float* W, const float* b, int act, float* pre,
+                 float* y, int M, int N, int K);
+size_t k_se_fc_bwd_scratch_floats(int B, int mid, int rd);
+int k_se_fc_bwd(hipStream_t st, const float* dgate, const float* gpre, const float* r, const float* rpre,
+                const float* pool, const float* We, const float* Wr, float* dWe, float* dbe, float* dWr, float* dbr,
+                float* dpool, float* scratch, int scratch_is_zero, int B, int mid, int rd);

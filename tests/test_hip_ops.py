@@ -752,3 +752,47 @@ def test_squeeze_excite_and_block_end_kernels():
     L.check(L.lib().mmvqa_bn_act_add(L.stream_ptr(), P(zd), P(scd), P(shd), L.ACT_NONE, None, None, None, 0, 0, P(o), N * HW, Cc))
     torch.cuda.synchronize()
     assert_close(o, (z * sc + sh).view(-1, Cc), TOL, "bn_act_add plain")
+
+
+@pytest.mark.parametrize("B,mid,rd", [(16, 1824, 76), (3, 88, 22), (37, 640, 40), (64, 3072, 128), (2, 50, 13)])
+def test_squeeze_excite_fc_layers(B, mid, rd):
+    """the two fully connected layers of the squeeze-excite gate (timm SqueezeExcite: conv_reduce -> SiLU ->
+    conv_expand -> sigmoid on the pooled [B, mid] tensor), forward and every gradient vs plain torch; full-size
+    tf_efficientnetv2_m shapes, batches that are not a multiple of 16, channel counts that are not multiples of 4/64;
+    weight and bias gradients ACCUMULATE into what is already there"""
+    torch.manual_seed(B * 1000 + rd)
+    pool = torch.randn(B, mid, requires_grad=True)
+    Wr = (torch.randn(rd, mid) / mid ** 0.5).requires_grad_(True)
+    br = (torch.randn(rd) * 0.1).requires_grad_(True)
+    We = (torch.randn(mid, rd) / rd ** 0.5).requires_grad_(True)
+    be = (torch.randn(mid) * 0.1).requires_grad_(True)
+    rpre_ref = pool @ Wr.t() + br
+    r_ref = F.silu(rpre_ref)
+    gpre_ref = r_ref @ We.t() + be
+    gate_ref = torch.sigmoid(gpre_ref)
+    dgate = torch.randn(B, mid)
+    gate_ref.backward(dgate)
+    d = lambda x: x.detach().contiguous().to(dev())  # noqa: E731
+    pool_d, Wr_d, br_d, We_d, be_d, dgate_d = d(pool), d(Wr), d(br), d(We), d(be), d(dgate)
+    rpre, r = torch.zeros(B, rd, device=dev()), torch.zeros(B, rd, device=dev())
+    gpre, gate = torch.zeros(B, mid, device=dev()), torch.zeros(B, mid, device=dev())
+    L.check(L.lib().mmvqa_se_fc_fwd(L.stream_ptr(), P(pool_d), P(Wr_d), P(br_d), P(We_d), P(be_d), P(rpre), P(r), P(gpre),
+                                    P(gate), B, mid, rd))
+    torch.cuda.synchronize()
+    assert_close(rpre, rpre_ref.detach(), TOL, "rpre")
+    assert_close(r, r_ref.detach(), TOL, "r")
+    assert_close(gpre, gpre_ref.detach(), TOL, "gpre")
+    assert_close(gate, gate_ref.detach(), TOL, "gate")
+    base = [torch.randn(mid, rd), torch.randn(mid), torch.randn(rd, mid), torch.randn(rd)]   # gradients already there
+    dWe, dbe, dWr, dbr = (x.clone().to(dev()) for x in base)
+    dpool = torch.full((B, mid), float("nan"), device=dev())
+    n = L.lib().mmvqa_se_fc_bwd_scratch_floats(B, mid, rd)
+    scratch = torch.full((n,), float("nan"), device=dev())
+    L.check(L.lib().mmvqa_se_fc_bwd(L.stream_ptr(), P(dgate_d), P(gpre), P(r), P(rpre), P(pool_d), P(We_d), P(Wr_d), P(dWe),
+                                    P(dbe), P(dWr), P(dbr), P(dpool), P(scratch), B, mid, rd))
+    torch.cuda.synchronize()
+    assert_close(dpool, pool.grad, TOL, "dpool")
+    assert_close(dWe.cpu() - base[0], We.grad, TOL, "dWe")
+    assert_close(dbe.cpu() - base[1], be.grad, TOL, "dbe")
+    assert_close(dWr.cpu() - base[2], Wr.grad, TOL, "dWr")
+    assert_close(dbr.cpu() - base[3], br.grad, TOL, "dbr")

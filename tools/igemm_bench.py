@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--filter", default="")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--nopro", action="store_true", help="plain operand loads (no BN prologue): prices the fused prologues")
+    ap.add_argument("--nostat", action="store_true", help="forward without the statistics epilogue")
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(",")]
     tot = {}
@@ -70,17 +72,21 @@ def main():
             for tile in tiles:
                 if kind == "fwd":
                     d, _, _ = conv_desc_fwd(x, w, N, H, W, Cin, Cout, K, s, p, z)
-                    d.a_pro, d.a_c0, d.a_c1 = L.PRO_AFFINE_RELU, P(sc), P(sh)
-                    d.stat1 = P(stat)
+                    if not a.nopro:
+                        d.a_pro, d.a_c0, d.a_c1 = L.PRO_AFFINE_RELU, P(sc), P(sh)
+                    if not a.nostat:
+                        d.stat1 = P(stat)
                     kd = L.KIND_FWD
                 elif kind == "dgrad":
                     d = conv_desc_dgrad(g, w, N, H, W, Cin, Cout, K, s, p, dx)
-                    d.A2, d.a_pro, d.a_c0, d.a_c1, d.a_c2 = P(z), L.PRO_DZ, P(c3[0]), P(c3[1]), P(c3[2])
+                    if not a.nopro:
+                        d.A2, d.a_pro, d.a_c0, d.a_c1, d.a_c2 = P(z), L.PRO_DZ, P(c3[0]), P(c3[1]), P(c3[2])
                     kd = L.KIND_DGRAD
                 else:
                     d = conv_desc_wgrad(g, x, N, H, W, Cin, Cout, K, s, p, dw)
-                    d.A2, d.a_pro, d.a_c0, d.a_c1, d.a_c2 = P(z), L.PRO_DZ, P(c3[0]), P(c3[1]), P(c3[2])
-                    d.b_pro, d.b_c0, d.b_c1 = L.PRO_AFFINE_RELU, P(sc), P(sh)
+                    if not a.nopro:
+                        d.A2, d.a_pro, d.a_c0, d.a_c1, d.a_c2 = P(z), L.PRO_DZ, P(c3[0]), P(c3[1]), P(c3[2])
+                        d.b_pro, d.b_c0, d.b_c1 = L.PRO_AFFINE_RELU, P(sc), P(sh)
                     if K > 1 and s == 1 and OH == H:
                         tab = torch.zeros(N * OH * OW, dtype=torch.int32, device=dev())
                         L.check(L.lib().mmvqa_pixmask(L.stream_ptr(), P(tab), N, OH, OW, H, W, K, K, s, p))
