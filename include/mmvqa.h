@@ -96,6 +96,11 @@ typedef struct mmvqa_gemm_desc {
   int mk_mode;       /* 0: ReLU mask (Mk*s+b > 0), 1: multiply by SiLU'(Mk*s+b) */
   const int* pixmask; /* optional, KIND_WGRAD of a stride-1 "same" convolution: per output pixel the bit mask of filter
                          taps that fall inside the image (mmvqa_pixmask); enables the uniform-tap weight-gradient loaders */
+  float* sk_ws;       /* optional, KIND_FWD / KIND_DGRAD: scratch of sk_ws_floats floats.  With it a launch that has few
+                         output tiles and a long contraction may split K over workgroups (splitk, or the launcher's /
+                         tuner's choice when splitk <= 0): partial tiles go to the scratch and a second launch sums them
+                         and applies the whole epilogue.  Needs splitk * M * N <= sk_ws_floats; one stream at a time. */
+  long long sk_ws_floats;
 } mmvqa_gemm_desc;
 
 /* Fused attention (models/transformer.py:19-30 and models/realformer.py:30-45). */

@@ -41,6 +41,7 @@ class GemmDesc(C.Structure):
         ("invstd1", c_ptr),
         ("stat2", c_ptr), ("Z2", c_ptr), ("z2_ld", C.c_int), ("mean2", c_ptr), ("invstd2", c_ptr),
         ("colsum", c_ptr), ("gate", c_ptr), ("gate_hw", C.c_int), ("mk_mode", C.c_int), ("pixmask", c_ptr),
+        ("sk_ws", c_ptr), ("sk_ws_floats", C.c_longlong),
     ]
 
 

@@ -372,6 +372,7 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
   }
   }
   e->vis = a.f((size_t)5 * B * H);
+  for (int i = 0; i < 2; ++i) e->sk_ws[i] = a.f(SK_WS_FLOATS);   // split-K partial tiles (main / side stream)
   e->dvis = a.f((size_t)5 * B * H);
   e->du = a.f(max_tapM * H);
   for (int i = 0; i < 3; ++i) e->gbuf[i] = a.f(max_io);
@@ -475,6 +476,14 @@ static GemmParams gp_linear_geom() {
   return g;
 }
 
+// scratch for K split over workgroups (igemm.hip: partial tiles + finishing launch); one per stream
+static void set_sk(mmvqa_engine* e, hipStream_t st, GemmParams& g) {
+  static const bool off = getenv("MMVQA_NO_SK_WS") != nullptr;   // A/B switch: no K split of forward / data-gradient products
+  if (off) return;
+  g.sk_ws = WS(e->sk_ws[(e->side && st == e->side) ? 1 : 0]);
+  g.sk_ws_floats = (long long)SK_WS_FLOATS;
+}
+
 struct EpiOpt {
   const float* R = nullptr; int r_ld = 0;
   const float* Mk = nullptr; int mk_ld = 0; const float* mk_s = nullptr; const float* mk_b = nullptr; int mk_mode = 0;
@@ -505,6 +514,7 @@ static int lin_fwd(mmvqa_engine* e, hipStream_t st, const float* x, int x_ld, lo
   g.C = y; g.c_ld = y_ld; g.Cpre = pre;
   g.bias = L.b >= 0 ? PRM(L.b) : nullptr;
   g.act = act; g.drop_p = drop_p; g.drop_seed = seed; g.R = R; g.r_ld = r_ld;
+  set_sk(e, st, g);
   RUN(PROF_IGEMM, 2.0 * M * L.out * L.in, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
   return MMVQA_OK;
 }
@@ -530,6 +540,7 @@ static int lin_dgrad(mmvqa_engine* e, hipStream_t st, const float* dy, int dy_ld
       g.c_atomic = 1; g.splitk = sk;
     }
   }
+  set_sk(e, st, g);
   RUN(PROF_IGEMM, 2.0 * M * L.out * L.in, mmvqa_launch_igemm(g, KIND_DGRAD, 0, 0, st));
   return MMVQA_OK;
 }
@@ -595,6 +606,7 @@ static int conv_fwd(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const flo
   g.B = PRM(c.w); g.b_ld = g.K;
   g.C = z; g.c_ld = c.Cout;
   if (e->training) { g.stat1 = stat_ptr(e, bn_out.stat_f); g.stat_bwd = 0; }
+  set_sk(e, st, g);
   RUN(PROF_IGEMM, 2.0 * g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
   return bn_coef_fwd(e, st, bn_out);
 }
@@ -643,6 +655,7 @@ static int conv_dgrad(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const f
   g.B = PRM(c.w); g.b_ld = c.KH * c.KH * c.Cin; g.b_tapstride = c.Cin;
   g.C = dx; g.c_ld = c.Cin;
   apply_epi(e, g, o);
+  set_sk(e, st, g);
   RUN(PROF_IGEMM, 2.0 * (double)N * OH * OW * c.Cout * c.KH * c.KH * c.Cin,
       mmvqa_launch_igemm(g, KIND_DGRAD, 0, 0, st));
   return MMVQA_OK;
@@ -662,6 +675,7 @@ static int tap_fwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, co
   g.epi_mode = EPI_TAP_FWD; g.act = tap_act(e); g.tap_HW = t.HW;
   g.tap_out = WS(e->vis) + (size_t)k * e->B * e->d.hidden;
   g.C = g.tap_out; g.c_ld = g.N;  // unused by this epilogue
+  set_sk(e, st, g);
   RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
   return MMVQA_OK;
 }
@@ -680,6 +694,7 @@ static int tap_bwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, co
   g.epi_mode = EPI_TAP_BWD; g.act = tap_act(e); g.tap_HW = t.HW;
   g.tap_dv = WS(e->dvis) + (size_t)k * e->B * Hd;
   g.C = WS(e->du); g.c_ld = Hd;
+  set_sk(e, st, g);
   RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
   // dW_tap[Hd][C] += du^T fmap
   GemmParams w = gp_linear_geom();
@@ -696,6 +711,7 @@ static int tap_bwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, co
   dg.B = PRM(t.w); dg.b_ld = t.C;
   dg.C = dfmap; dg.c_ld = t.C;
   apply_epi(e, dg, o);
+  set_sk(e, st, dg);
   RUN(PROF_IGEMM, 2.0 * (double)dg.M * dg.N * dg.K, mmvqa_launch_igemm(dg, KIND_DGRAD, 0, 0, st));
   return MMVQA_OK;
 }
@@ -953,6 +969,7 @@ static int eff_conv_fwd(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const
   g.B = PRM(c.w); g.b_ld = g.K;
   g.C = z; g.c_ld = c.Cout;
   if (e->training) { g.stat1 = stat_ptr(e, bn_out.stat_f); g.stat_bwd = 0; }
+  set_sk(e, st, g);
   RUN(PROF_IGEMM, 2.0 * g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
   return bn_coef_fwd(e, st, bn_out);
 }

@@ -88,6 +88,8 @@ enum { PROF_IGEMM = 0, PROF_ATTN = 1, PROF_OTHER = 2, PROF_NCLS = 3 };
 enum { REG_BACKBONE = 0, REG_TAP = 1, REG_QKV = 2, REG_ATTN = 3, REG_ENC = 4, REG_HEAD = 5, REG_EMBED = 6,
        REG_BNCOEF = 7, REG_N = 8 };
 
+constexpr size_t SK_WS_FLOATS = (size_t)8 << 20;   // 32 MB: 8 splits of a 224-tile (64x64) product
+
 struct mmvqa_engine {
   mmvqa_model_desc d;
   std::vector<TensorSpec> specs;
@@ -99,6 +101,7 @@ struct mmvqa_engine {
   std::vector<BlockRef> blocks;
   std::vector<EffBlock> eff;     // EfficientNetV2 body (cnn == 1)
   size_t eff_a0 = 0;             // materialised stem activation silu(bn1(conv_stem))
+  size_t sk_ws[2] = {0, 0};      // split-K partial-tile scratch per stream (igemm sk_ws)
   size_t eff_gA = 0, eff_gB = 0, eff_separt = 0, eff_se[6];   // backward scratch ([pixels, mid] x2, squeeze-excite temporaries)
   int layer_end[4];          // index of last block of layer1..4
   TapRef taps[5];            // order of the reference's return tuple: conv2(l4),conv3(l3),conv4(l2),conv5(l1),conv7(stem)

@@ -37,6 +37,7 @@ struct GemmAux {
   FastDiv ohw, ow;
   int fast;   // 0: general loaders | 1: uniform-tap loaders | 2: uniform-tap loaders with a halo mask (host-decided)
   int stagger;   // 8-wave variant: the second wave group runs its VALU/LDS-write block first (0 = off, for A/B timing)
+  float* part;   // split-K over workgroups with a finishing launch: partial tiles [split][M][N] go here, no epilogue
 };
 
 __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
@@ -107,6 +108,177 @@ extern "C" int mmvqa_debug_set_trace(unsigned long long* buf) {
 #define TRACE_STALL_DECL
 #define TRACE_STALL_FLUSH() do {} while (0)
 #endif
+
+// general epilogue of one BM x BN output tile: +bias -> Cpre -> *act'(Pre) -> act -> dropout -> +R -> ReLU mask -> store
+// -> statistics.  src(rl, c4) yields columns c4*4..+3 of tile row rl: the LDS-staged accumulators in the GEMM kernel,
+// the sum of the partial tiles in the split-K finishing kernel.  smem: BN*3 doubles + BN floats for the reductions
+// (free to overwrite once every thread has read its rows).
+template <int BM, int BN, int NT, class Src>
+__device__ __forceinline__ void general_epilogue(const GemmParams& p, int m0, int n0, int tid, float* smem, Src src) {
+  constexpr int CH = BN / 4;            // float4 chunks per tile row
+  constexpr int RP = NT / CH;           // rows per pass of the whole workgroup
+  constexpr int NPASS = BM / RP;
+  const int M = p.M, N = p.N;
+  const int c4 = tid % CH, rg = tid / CH;
+  const int col = n0 + c4 * 4;
+  const bool full = col + 3 < N;          // whole float4 inside the matrix
+  auto ldv = [&](const float* base, size_t off) __attribute__((always_inline)) {
+    f32x4 r = {0, 0, 0, 0};
+    if (full && !(off & 3)) r = ld4(base + off);
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (col + j < N) r[j] = base[off + j];
+    }
+    return r;
+  };
+  auto stv = [&](float* base, size_t off, f32x4 v) __attribute__((always_inline)) {
+    if (full && !(off & 3)) *reinterpret_cast<f32x4*>(base + off) = v;
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (col + j < N) base[off + j] = v[j];
+    }
+  };
+  {
+    float* C = p.C; const int ldc = p.c_ld;
+    float* Cpre = p.Cpre;
+    const float* Pre = p.Pre; const int dact = p.dact, pre_ld = p.pre_ld, act = p.act;
+    const float* R = p.R; const int r_ld = p.r_ld;
+    const float* Mk = p.Mk; const int mk_ld = p.mk_ld, mk_mode = p.mk_mode;
+    const float* Z1 = p.Z1; const float* Z2 = p.Z2; const int z1_ld = p.z1_ld, z2_ld = p.z2_ld;
+    double* st1 = p.stat1; double* st2 = p.stat2; const int stat_bwd = p.stat_bwd;
+    float* colsum = p.colsum;
+    const float drop_p = p.drop_p; const uint32_t drop_seed = p.drop_seed;
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+    const bool cok = col < N;
+    f32x4 bias = {0, 0, 0, 0}, mks = {1, 1, 1, 1}, mkb = {0, 0, 0, 0};
+    f32x4 mu1 = {0, 0, 0, 0}, is1 = {0, 0, 0, 0}, mu2 = {0, 0, 0, 0}, is2 = {0, 0, 0, 0};
+    if (cok) {
+      if (p.bias) bias = ldv(p.bias, col);
+      if (Mk && p.mk_s) { mks = ldv(p.mk_s, col); mkb = ldv(p.mk_b, col); }
+      if (st1 && stat_bwd) { mu1 = ldv(p.mean1, col); is1 = ldv(p.invstd1, col); }
+      if (st2) { mu2 = ldv(p.mean2, col); is2 = ldv(p.invstd2, col); }
+    }
+    // Per-thread partial sums stay in fp32 (at most BM/RP rows each); they are widened to fp64 when they
+    // meet the other row groups.  The passes run in blocks of UP with every side-tensor load of a block
+    // issued before its first use: one pass at a time paid a full memory latency per pass (phase trace:
+    // 3 us for the 4 passes of a 64x64 tile).
+    f32x4 sa = {0, 0, 0, 0}, sb = {0, 0, 0, 0}, sc = {0, 0, 0, 0}, cs = {0, 0, 0, 0};
+    TRACE_EPI(3);
+    constexpr int UP = NPASS < 4 ? NPASS : 4;
+#pragma unroll 1
+    for (int ps0 = 0; ps0 < NPASS; ps0 += UP) {
+      if (m0 + rg + ps0 * RP >= M || !cok) break;
+      f32x4 vv[UP], pr[UP], rr[UP], mm[UP], zz[UP], zz2[UP];
+      bool ok[UP];
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        const int rl = rg + (ps0 + u) * RP, row = m0 + rl;
+        ok[u] = row < M;
+        const size_t rw = ok[u] ? (size_t)row : (size_t)m0;   // clamped: loads of a row past the end are discarded
+        vv[u] = src(rl, c4);
+        if (dact) pr[u] = ldv(Pre, rw * pre_ld + col);
+        if (R) rr[u] = ldv(R, rw * r_ld + col);
+        if (Mk) mm[u] = ldv(Mk, rw * mk_ld + col);
+        if (st1 && stat_bwd) {
+          zz[u] = ldv(Z1, rw * z1_ld + col);
+          if (st2) zz2[u] = ldv(Z2, rw * z2_ld + col);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        if (!ok[u]) continue;
+        const int row = m0 + rg + (ps0 + u) * RP;
+        f32x4 v = vv[u] + bias;
+        if (Cpre) stv(Cpre, (size_t)row * ldc + col, v);
+        if (dact) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= act_bwd(dact, pr[u][j]);
+        }
+        if (act) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = act_fwd(act, v[j]);
+        }
+        if (drop_p > 0.f) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float uu = rng_uniform(drop_seed, (uint32_t)row * (uint32_t)N + (uint32_t)(col + j));
+            v[j] = (uu >= drop_p) ? v[j] * keep_scale : 0.f;
+          }
+        }
+        if (R) v += rr[u];
+        if (Mk) {
+          if (mk_mode == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (mm[u][j] * mks[j] + mkb[j] > 0.f) ? v[j] : 0.f;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= dsilu_f(mm[u][j] * mks[j] + mkb[j]);
+          }
+        }
+#ifndef EXP_NOSTOREC
+        stv(C, (size_t)row * ldc + col, v);
+#endif
+        if (st1) {
+          if (stat_bwd) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sa[j] += v[j]; sb[j] += v[j] * ((zz[u][j] - mu1[j]) * is1[j]); }
+            if (st2) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sc[j] += v[j] * ((zz2[u][j] - mu2[j]) * is2[j]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sa[j] += v[j]; sb[j] += v[j] * v[j]; }
+          }
+        }
+        if (colsum) cs += v;
+      }
+    }
+    TRACE_EPI(1);
+    if (st1 || colsum) {
+      // combine the RP row groups of the workgroup with LDS atomics (fp64 for the statistics), then ONE global
+      // atomic per column and statistic
+      __syncthreads();                       // everyone is done reading ctile
+      double* red = reinterpret_cast<double*>(smem);   // [BN][3]
+      float* redf = smem + BN * 6;                      // [BN]
+      for (int i = tid; i < BN * 3; i += NT) red[i] = 0.0;
+      for (int i = tid; i < BN; i += NT) redf[i] = 0.f;
+      __syncthreads();
+      if (cok) {
+        if (st1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            double* d = red + (c4 * 4 + j) * 3;
+            atomicAdd(d, (double)sa[j]);
+            atomicAdd(d + 1, (double)sb[j]);
+            if (st2) atomicAdd(d + 2, (double)sc[j]);
+          }
+        }
+        if (colsum) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicAdd(&redf[c4 * 4 + j], cs[j]);
+        }
+      }
+      __syncthreads();
+      TRACE_EPI(2);
+      if (tid < BN && n0 + tid < N) {
+        if (st1) {
+          const double* d = red + tid * 3;
+          const int slot = (blockIdx.y + blockIdx.x * 7 + blockIdx.z * 3) & (MMVQA_STAT_SLOTS - 1);
+          double* d1 = st1 + ((size_t)slot * N + n0 + tid) * 2;
+          atomicAdd(d1, d[0]);
+          atomicAdd(d1 + 1, d[1]);
+          if (st2) {
+            double* d2 = st2 + ((size_t)slot * N + n0 + tid) * 2;
+            atomicAdd(d2, d[0]);
+            atomicAdd(d2 + 1, d[2]);
+          }
+        }
+        if (colsum) atomicAdd(&colsum[n0 + tid], redf[tid]);
+      }
+    }
+    }
+}
 
 // KS = intra-workgroup split of every K-tile over KS groups of 4 waves (KS*256 threads): for problems
 // with fewer workgroups than CUs it doubles the waves per SIMD (latency hiding) at the price of one
@@ -1054,6 +1226,19 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     }
   };
 
+  if (x.part) {
+    // split-K over workgroups, finished by splitk_finish_kernel: this workgroup's partial tile, row-wise 16-byte stores
+    float* P = x.part + (size_t)blockIdx.z * M * N;
+#pragma unroll 1
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int rl = rg + ps * RP, row = m0 + rl;
+      if (row >= M || col >= N) break;
+      stv(P, (size_t)row * N + col, *reinterpret_cast<const f32x4*>(&ctile[rl * LDC + c4 * 4]));
+    }
+    TRACE_MARK(4);
+    return;
+  }
+
   if (p.c_atomic) {
     // accumulate (weight gradients / split-K): one float per lane so that a wave-instruction adds to
     // 256 contiguous bytes (MI355X_MICROARCH "Global float atomics": full rate only in that shape)
@@ -1134,148 +1319,40 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     return;
   }
 
-  // general epilogue: +bias -> Cpre -> *act'(Pre) -> act -> dropout -> +R -> ReLU mask -> store -> statistics
-  {
-    float* C = p.C; const int ldc = p.c_ld;
-    float* Cpre = p.Cpre;
-    const float* Pre = p.Pre; const int dact = p.dact, pre_ld = p.pre_ld, act = p.act;
-    const float* R = p.R; const int r_ld = p.r_ld;
-    const float* Mk = p.Mk; const int mk_ld = p.mk_ld, mk_mode = p.mk_mode;
-    const float* Z1 = p.Z1; const float* Z2 = p.Z2; const int z1_ld = p.z1_ld, z2_ld = p.z2_ld;
-    double* st1 = p.stat1; double* st2 = p.stat2; const int stat_bwd = p.stat_bwd;
-    float* colsum = p.colsum;
-    const float drop_p = p.drop_p; const uint32_t drop_seed = p.drop_seed;
-    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
-    const bool cok = col < N;
-    f32x4 bias = {0, 0, 0, 0}, mks = {1, 1, 1, 1}, mkb = {0, 0, 0, 0};
-    f32x4 mu1 = {0, 0, 0, 0}, is1 = {0, 0, 0, 0}, mu2 = {0, 0, 0, 0}, is2 = {0, 0, 0, 0};
-    if (cok) {
-      if (p.bias) bias = ldv(p.bias, col);
-      if (Mk && p.mk_s) { mks = ldv(p.mk_s, col); mkb = ldv(p.mk_b, col); }
-      if (st1 && stat_bwd) { mu1 = ldv(p.mean1, col); is1 = ldv(p.invstd1, col); }
-      if (st2) { mu2 = ldv(p.mean2, col); is2 = ldv(p.invstd2, col); }
-    }
-    // Per-thread partial sums stay in fp32 (at most BM/RP rows each); they are widened to fp64 when they
-    // meet the other row groups.  The passes run in blocks of UP with every side-tensor load of a block
-    // issued before its first use: one pass at a time paid a full memory latency per pass (phase trace:
-    // 3 us for the 4 passes of a 64x64 tile).
-    f32x4 sa = {0, 0, 0, 0}, sb = {0, 0, 0, 0}, sc = {0, 0, 0, 0}, cs = {0, 0, 0, 0};
-    TRACE_EPI(3);
-    constexpr int UP = NPASS < 4 ? NPASS : 4;
-#pragma unroll 1
-    for (int ps0 = 0; ps0 < NPASS; ps0 += UP) {
-      if (m0 + rg + ps0 * RP >= M || !cok) break;
-      f32x4 vv[UP], pr[UP], rr[UP], mm[UP], zz[UP], zz2[UP];
-      bool ok[UP];
-#pragma unroll
-      for (int u = 0; u < UP; ++u) {
-        const int rl = rg + (ps0 + u) * RP, row = m0 + rl;
-        ok[u] = row < M;
-        const size_t rw = ok[u] ? (size_t)row : (size_t)m0;   // clamped: loads of a row past the end are discarded
-        vv[u] = *reinterpret_cast<const f32x4*>(&ctile[rl * LDC + c4 * 4]);
-        if (dact) pr[u] = ldv(Pre, rw * pre_ld + col);
-        if (R) rr[u] = ldv(R, rw * r_ld + col);
-        if (Mk) mm[u] = ldv(Mk, rw * mk_ld + col);
-        if (st1 && stat_bwd) {
-          zz[u] = ldv(Z1, rw * z1_ld + col);
-          if (st2) zz2[u] = ldv(Z2, rw * z2_ld + col);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UP; ++u) {
-        if (!ok[u]) continue;
-        const int row = m0 + rg + (ps0 + u) * RP;
-        f32x4 v = vv[u] + bias;
-        if (Cpre) stv(Cpre, (size_t)row * ldc + col, v);
-        if (dact) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] *= act_bwd(dact, pr[u][j]);
-        }
-        if (act) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = act_fwd(act, v[j]);
-        }
-        if (drop_p > 0.f) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float uu = rng_uniform(drop_seed, (uint32_t)row * (uint32_t)N + (uint32_t)(col + j));
-            v[j] = (uu >= drop_p) ? v[j] * keep_scale : 0.f;
-          }
-        }
-        if (R) v += rr[u];
-        if (Mk) {
-          if (mk_mode == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (mm[u][j] * mks[j] + mkb[j] > 0.f) ? v[j] : 0.f;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= dsilu_f(mm[u][j] * mks[j] + mkb[j]);
-          }
-        }
-#ifndef EXP_NOSTOREC
-        stv(C, (size_t)row * ldc + col, v);
-#endif
-        if (st1) {
-          if (stat_bwd) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { sa[j] += v[j]; sb[j] += v[j] * ((zz[u][j] - mu1[j]) * is1[j]); }
-            if (st2) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) sc[j] += v[j] * ((zz2[u][j] - mu2[j]) * is2[j]);
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { sa[j] += v[j]; sb[j] += v[j] * v[j]; }
-          }
-        }
-        if (colsum) cs += v;
-      }
-    }
-    TRACE_EPI(1);
-    if (st1 || colsum) {
-      // combine the RP row groups of the workgroup with LDS atomics (fp64 for the statistics), then ONE global
-      // atomic per column and statistic
-      __syncthreads();                       // everyone is done reading ctile
-      double* red = reinterpret_cast<double*>(smem);   // [BN][3]
-      float* redf = smem + BN * 6;                      // [BN]
-      for (int i = tid; i < BN * 3; i += NT) red[i] = 0.0;
-      for (int i = tid; i < BN; i += NT) redf[i] = 0.f;
-      __syncthreads();
-      if (cok) {
-        if (st1) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            double* d = red + (c4 * 4 + j) * 3;
-            atomicAdd(d, (double)sa[j]);
-            atomicAdd(d + 1, (double)sb[j]);
-            if (st2) atomicAdd(d + 2, (double)sc[j]);
-          }
-        }
-        if (colsum) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) atomicAdd(&redf[c4 * 4 + j], cs[j]);
-        }
-      }
-      __syncthreads();
-      TRACE_EPI(2);
-      if (tid < BN && n0 + tid < N) {
-        if (st1) {
-          const double* d = red + tid * 3;
-          const int slot = (blockIdx.y + blockIdx.x * 7 + blockIdx.z * 3) & (MMVQA_STAT_SLOTS - 1);
-          double* d1 = st1 + ((size_t)slot * N + n0 + tid) * 2;
-          atomicAdd(d1, d[0]);
-          atomicAdd(d1 + 1, d[1]);
-          if (st2) {
-            double* d2 = st2 + ((size_t)slot * N + n0 + tid) * 2;
-            atomicAdd(d2, d[0]);
-            atomicAdd(d2 + 1, d[2]);
-          }
-        }
-        if (colsum) atomicAdd(&colsum[n0 + tid], redf[tid]);
-      }
-    }
-  }
+  general_epilogue<BM, BN, NT>(p, m0, n0, tid, smem,
+                               [&](int rl, int cq) __attribute__((always_inline)) {
+                                 return *reinterpret_cast<const f32x4*>(&ctile[rl * LDC + cq * 4]);
+                               });
   TRACE_MARK(4);
+}
+
+// Second launch of a split-K FWD / DGRAD product: sums the partial tiles [nsplit][M][N] and runs the general epilogue
+// (statistics included) exactly as the single-launch kernel does on its accumulators.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmParams p, const float* __restrict__ part,
+                                                            int nsplit) {
+  constexpr int BM = 64, BN = 64;
+  __shared__ double smem_d[BN * 3 + BN / 2 + 2];
+  const int tid = threadIdx.x, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int M = p.M, N = p.N;
+  const size_t MN = (size_t)M * N;
+  general_epilogue<BM, BN, 256>(p, m0, n0, tid, reinterpret_cast<float*>(smem_d),
+                                [&](int rl, int cq) __attribute__((always_inline)) {
+                                  f32x4 v = {0, 0, 0, 0};
+                                  const int row = m0 + rl, col = n0 + cq * 4;
+                                  if (row < M && col < N) {
+                                    const size_t off = (size_t)row * N + col;
+                                    if (col + 3 < N && !(off & 3)) {
+#pragma unroll 4
+                                      for (int s = 0; s < nsplit; ++s) v += ld4(part + s * MN + off);
+                                    } else {
+                                      for (int s = 0; s < nsplit; ++s)
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j)
+                                          if (col + j < N) v[j] += part[s * MN + off + j];
+                                    }
+                                  }
+                                  return v;
+                                });
 }
 
 // --------------------------------------------------------------------------- host launch
@@ -1315,6 +1392,7 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
   x.fast = 0;
   static const int stagger_on = getenv("MMVQA_IGEMM_NOSTAGGER") ? 0 : 1;
   x.stagger = stagger_on;
+  x.part = (KIND != KIND_WGRAD && !NCHW && p.splitk > 1 && !p.c_atomic) ? p.sk_ws : nullptr;
   if (!NCHW && (p.K % BK == 0 || (KIND == KIND_WGRAD && p.pixmask)) && !p.gate && !getenv("MMVQA_IGEMM_GENERAL")) {
     const int taps = p.g_KH * p.g_KW;
     const double lim = 2147483648.0 - 16777216.0;
@@ -1346,10 +1424,21 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
             BM, BN, BK, KS, p.M, p.N, p.K, p.g_Cs, p.g_KH * p.g_KW, p.g_stride, p.a_pro, p.b_pro, p.splitk);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, KIND, NCHW, KS>), grid, dim3(256 * KS), smem, stream, p, x);
   KERNEL_CHECK_RET();
+  if (x.part) {
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((p.N + 63) / 64, (p.M + 63) / 64), dim3(256), 0, stream, p, x.part,
+                       p.splitk);
+    KERNEL_CHECK_RET();
+  }
   return MMVQA_OK;
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// split-K of a forward / data-gradient product over workgroups (partial tiles + finishing launch): the caller gave a
+// scratch, the epilogue is the general one, nothing accumulates into C
+static bool sk_eligible(const GemmParams& p, int kind) {
+  return kind != KIND_WGRAD && p.sk_ws && p.sk_ws_floats > 0 && p.epi_mode == EPI_PLAIN && !p.c_atomic;
+}
 
 // --------------------------------------------------------------------------- per-shape tuner
 // With tile == 0 the launcher consults the active tuner (set by the engine around forward/backward):
@@ -1365,7 +1454,7 @@ static std::string tune_key(const GemmParams& p, int kind, int nchw) {
   snprintf(buf, sizeof(buf), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", kind, nchw, p.M, p.N, p.K,
            p.g_KH * p.g_KW, p.g_stride, p.g_Cs, p.a_pro, p.b_pro, p.epi_mode, p.act | (p.dact << 4),
            (p.stat1 ? 1 : 0) | (p.stat2 ? 2 : 0) | (p.Mk ? 4 : 0) | (p.R ? 8 : 0) | (p.Cpre ? 16 : 0) |
-               (p.colsum ? 32 : 0) | (p.bias ? 64 : 0),
+               (p.colsum ? 32 : 0) | (p.bias ? 64 : 0) | (p.sk_ws ? 128 : 0),
            p.c_atomic, p.splitk);
   return buf;
 }
@@ -1429,6 +1518,10 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
       for (int t : tiles_w) for (int sk : {0, 1, 2, 3, 4, 6, 8, 12, 16}) cands.push_back({t, sk});
     } else if (kind == KIND_WGRAD) {
       for (int t : tiles_w) cands.push_back({t, p.splitk});
+    } else if (sk_eligible(p, kind) && p.splitk <= 0 && (long)cdiv(p.M, 64) * cdiv(p.N, 64) <= 224) {
+      // few output tiles: also try K split over workgroups with a finishing launch (needs the caller's scratch)
+      for (int t : {3, 5, 6}) for (int sk : {1, 2, 3, 4, 6, 8}) cands.push_back({t, sk});
+      for (int t : {1, 2, 4}) cands.push_back({t, 1});
     } else {
       for (int t : tiles_f) cands.push_back({t, p.splitk});
     }
@@ -1493,11 +1586,27 @@ static int launch_one(GemmParams p, int kind, int nchw, int tile, hipStream_t st
       p.splitk = want < maxs ? want : maxs;
       if (p.splitk < 1) p.splitk = 1;
       if (p.splitk > 1) p.c_atomic = 1;
+    } else if (!nchw && sk_eligible(p, kind)) {
+      // untuned default: fill the chip when the tile grid is small and every split keeps >= 256 of K
+      const long tiles = (long)cdiv(p.M, bm) * cdiv(p.N, bn);
+      if (tiles <= 128 && p.K >= 1024) {
+        int want = (int)((256 + tiles - 1) / tiles);
+        const int maxs = p.K / 256;
+        if (want > maxs) want = maxs;
+        if (want > 8) want = 8;
+        if (want > 1) p.splitk = want;
+      }
     }
+  }
+  if (kind != KIND_WGRAD && !nchw && p.splitk > 1 && !p.c_atomic) {
+    if (!sk_eligible(p, kind))
+      return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: split-K needs an accumulating epilogue or a scratch (sk_ws)");
+    const long long cap = p.sk_ws_floats / ((long long)p.M * p.N);
+    if (p.splitk > cap) p.splitk = (int)(cap < 1 ? 1 : cap);
   }
   p.ktiles_per_split = cdiv(nkt, p.splitk);
   p.splitk = cdiv(nkt, p.ktiles_per_split);
-  if (p.splitk > 1 && !p.c_atomic)
+  if (p.splitk > 1 && !p.c_atomic && !(kind != KIND_WGRAD && !nchw && sk_eligible(p, kind)))
     return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: split-K needs an accumulating epilogue");
 #define GO(BM_, BN_, BK_)                                                                   \
   do {                                                                                      \

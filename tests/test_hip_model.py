@@ -195,11 +195,11 @@ def test_full_config3_and_4_effnetv2m_realformer_mlm_supcon_224():
 
 def test_full_config5_effnetv2m_realformer_vqa_asl():
     """BASELINE.json configs[4]: vqamed2019/train.py --loss=ASLSingleLabel, tf_efficientnetv2_m + RealFormer, VQA head
-    (masked mean-pool) with 1552 answer classes, T 28 (the script's default), full depth and width, batch 2; 160x160
+    (masked mean-pool) with 1552 answer classes, T 28 (the script's default), full depth and width, batch 2; 128x128
     images (the 224x224 backbone is the test above; this one is about the VQA head, ASL and T = 28 at full width)"""
     run_case(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer", heads=8, dataset="VQA-Med",
                          vocab_size=1552, emb_vocab=30522, hidden_dropout_prob=0.0, emb_dropout_prob=0.0,
-                         rf_dropout_prob=0.0), B=2, T=28, hw=160, kind="vqa", stat_tol=TOL)
+                         rf_dropout_prob=0.0), B=2, T=28, hw=128, kind="vqa", stat_tol=TOL)
 
 
 @pytest.mark.parametrize("tag,tm,ds,supcon,cnn,relu", MODEL_CASES)

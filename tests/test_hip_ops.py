@@ -232,6 +232,75 @@ def test_conv_fwd_bwd(cfg):
             assert_close(dw.view(Cout, K, K, Cin).permute(0, 3, 1, 2), wr.grad, TOL, f"wgrad (pixel table, tile {tile})")
 
 
+@pytest.mark.parametrize("cfg,tile", [((2, 7, 7, 256, 72, 1, 1, 0), 3), ((2, 7, 7, 256, 72, 1, 1, 0), 5), ((1, 7, 7, 128, 40, 3, 1, 1), 6),
+                                      ((3, 6, 6, 192, 52, 1, 1, 0), 3)])
+@pytest.mark.parametrize("splitk", [2, 3, 8])
+def test_conv_split_k_with_finishing_launch(cfg, tile, splitk):
+    """forward / data-gradient products with few output tiles and a long contraction: K split over workgroups into a
+    caller-provided scratch (sk_ws) + the finishing launch that sums the partial tiles and runs the WHOLE epilogue
+    (BN statistics forward and backward, ReLU mask, residual).  Same answers as the single launch and as torch; ragged
+    N (72, 52, 40: not multiples of 64), a split count that does not divide the K-tiles, and a
+    scratch too small for the requested split (the launcher lowers the split instead of overrunning it)."""
+    N, H, W, Cin, Cout, K, s, p = cfg
+    torch.manual_seed(5)
+    x_raw = torch.randn(N, Cin, H, W)
+    sc, sh = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.3
+    w = torch.randn(Cout, Cin, K, K) / math.sqrt(Cin * K * K)
+    a = torch.relu(x_raw * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    z_ref = F.conv2d(a, w, stride=s, padding=p)
+    OH, OW = z_ref.shape[2:]
+    xd, wd = nhwc(x_raw), w_ohwi(w)
+    scd, shd = sc.to(dev()), sh.to(dev())
+    M = N * OH * OW
+    ws = torch.full((splitk * M * Cout + 16,), float("nan"), device=dev())   # NaN: every partial element must be written
+    res = {}
+    for sk in (1, splitk):
+        z = torch.zeros(M, Cout, device=dev())
+        stat = torch.zeros(L.STAT_SLOTS, Cout, 2, dtype=torch.float64, device=dev())
+        d, _, _ = conv_desc_fwd(xd, wd, N, H, W, Cin, Cout, K, s, p, z)
+        d.a_pro, d.a_c0, d.a_c1 = L.PRO_AFFINE_RELU, P(scd), P(shd)
+        d.stat1, d.stat_bwd = P(stat), 0
+        d.splitk, d.sk_ws, d.sk_ws_floats = sk, P(ws), splitk * M * Cout
+        run_igemm(d, L.KIND_FWD, tile=tile)
+        res[sk] = (z, stat.sum(0).cpu())
+    assert_close(from_nhwc(res[splitk][0], N, OH, OW, Cout), z_ref, TOL, "z (split-K)")
+    assert_close(res[splitk][0], res[1][0], 1e-5, "z split vs single launch")
+    assert_close(res[splitk][1][:, 0], z_ref.sum(dim=(0, 2, 3)).double(), 1e-5, "sum")
+    assert_close(res[splitk][1][:, 1], (z_ref.double() ** 2).sum(dim=(0, 2, 3)), 1e-5, "sumsq")
+    # data gradient of the transposed role: gradient wrt a, ReLU mask of the producer, residual, backward statistics
+    G = torch.randn_like(z_ref)
+    z_ref.backward(G)
+    Gd = nhwc(G)
+    Rr = torch.randn(N * H * W, Cin)
+    Rd = Rr.to(dev())
+    mu, istd = torch.randn(Cin) * 0.1, torch.rand(Cin) + 0.5
+    mud, isd = mu.to(dev()), istd.to(dev())
+    M2 = N * H * W
+    ws2 = torch.full((splitk * M2 * Cin,), float("nan"), device=dev())
+    out = {}
+    for sk, cap in ((1, splitk * M2 * Cin), (splitk, splitk * M2 * Cin), (splitk, 2 * M2 * Cin)):
+        dx = torch.zeros(M2, Cin, device=dev())
+        bst = torch.zeros(L.STAT_SLOTS, Cin, 2, dtype=torch.float64, device=dev())
+        d = conv_desc_dgrad(Gd, wd, N, H, W, Cin, Cout, K, s, p, dx)
+        d.Mk, d.mk_ld, d.mk_s, d.mk_b = P(xd), Cin, P(scd), P(shd)
+        d.R, d.r_ld = P(Rd), Cin
+        d.stat1, d.stat_bwd, d.Z1, d.z1_ld, d.mean1, d.invstd1 = P(bst), 1, P(xd), Cin, P(mud), P(isd)
+        d.splitk, d.sk_ws, d.sk_ws_floats = sk, P(ws2), cap
+        run_igemm(d, L.KIND_DGRAD, tile=tile)
+        out[(sk, cap)] = (dx, bst.sum(0).cpu())
+    mask = (x_raw * sc[None, :, None, None] + sh[None, :, None, None] > 0).float()
+    g_ref = (a.grad + Rr.view(N, H, W, Cin).permute(0, 3, 1, 2)) * mask
+    xhat = (x_raw - mu[None, :, None, None]) * istd[None, :, None, None]
+    for key, (dx, bs) in out.items():
+        assert_close(from_nhwc(dx, N, H, W, Cin), g_ref, TOL, f"dgrad {key}")
+        assert_close(bs[:, 0], g_ref.sum(dim=(0, 2, 3)).double(), 1e-4, f"sum g {key}")
+        assert_close(bs[:, 1], (g_ref * xhat).sum(dim=(0, 2, 3)).double(), 1e-4, f"sum g xhat {key}")
+    # without a scratch a split forward product is refused, not silently run unsplit
+    d, _, _ = conv_desc_fwd(xd, wd, N, H, W, Cin, Cout, K, s, p, res[1][0])
+    d.splitk = 2
+    assert L.lib().mmvqa_igemm(C.byref(d), L.KIND_FWD, 0, tile, L.stream_ptr()) != 0
+
+
 def test_stem_conv():
     torch.manual_seed(3)
     N, H, W, Cout = 2, 20, 22, 16
