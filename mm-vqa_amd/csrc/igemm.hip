@@ -1326,6 +1326,8 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
   TRACE_MARK(4);
 }
 
+constexpr int SK_MAX = 8;   // most workgroups one output tile's K range is split over (finishing-launch form)
+
 // Second launch of a split-K FWD / DGRAD product: sums the partial tiles [nsplit][M][N] and runs the general epilogue
 // (statistics included) exactly as the single-launch kernel does on its accumulators.
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmParams p, const float* __restrict__ part,
@@ -1342,8 +1344,14 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmParams p, 
                                   if (row < M && col < N) {
                                     const size_t off = (size_t)row * N + col;
                                     if (col + 3 < N && !(off & 3)) {
-#pragma unroll 4
-                                      for (int s = 0; s < nsplit; ++s) v += ld4(part + s * MN + off);
+                                      // all partial tiles of the row in flight at once (the launcher caps the split
+                                      // at SK_MAX): a runtime-bounded loop paid one memory latency per few splits
+                                      f32x4 t[SK_MAX];
+#pragma unroll
+                                      for (int s = 0; s < SK_MAX; ++s)
+                                        t[s] = s < nsplit ? ld4(part + s * MN + off) : f32x4{0, 0, 0, 0};
+#pragma unroll
+                                      for (int s = 0; s < SK_MAX; ++s) v += t[s];
                                     } else {
                                       for (int s = 0; s < nsplit; ++s)
 #pragma unroll
@@ -1603,6 +1611,7 @@ static int launch_one(GemmParams p, int kind, int nchw, int tile, hipStream_t st
       return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: split-K needs an accumulating epilogue or a scratch (sk_ws)");
     const long long cap = p.sk_ws_floats / ((long long)p.M * p.N);
     if (p.splitk > cap) p.splitk = (int)(cap < 1 ? 1 : cap);
+    if (p.splitk > SK_MAX) p.splitk = SK_MAX;
   }
   p.ktiles_per_split = cdiv(nkt, p.splitk);
   p.splitk = cdiv(nkt, p.ktiles_per_split);
