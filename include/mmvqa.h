@@ -240,6 +240,13 @@ int mmvqa_dwconv_bwd_weight(mmvqa_stream_t s, const float* g2, const float* z2, 
 int mmvqa_se_pool(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, float* pool, int N, int HW, int C);
 int mmvqa_se_dgate(mmvqa_stream_t s, const float* t, const float* z, const float* sc, const float* sh, float* dgate,
                    int N, int HW, int C);
+/* visual-token tap of a feature map with few channels (models/image_encoding.py:53-62 at the stem: conv1x1 C -> N,
+ * activation, global average pool): out[img][n] += mean_hw act(sum_c x'[pix][c] W[n][c]) with x' = x, or
+ * relu(x*sc+sh) when sc/sh are given; x [M, C] NHWC rows, M = images*HW.  C in {24, 64}, M and HW multiples of 32,
+ * M >= 32768 (mmvqa_tap_thin_ok); `out` [images, N] must be zero on entry. */
+int mmvqa_tap_thin_ok(long M, int N, int C, int HW);
+int mmvqa_tap_thin_fwd(mmvqa_stream_t s, const float* x, const float* sc, const float* sh, const float* W, float* out,
+                       long M, int N, int C, int HW, int act);
 /* squeeze-excite fully connected layers (timm SqueezeExcite conv_reduce / conv_expand on the pooled [B, mid] tensor):
  *   rpre = pool Wr^T + br, r = silu(rpre)   [B, rd]   Wr [rd, mid]
  *   gpre = r We^T + be,    gate = sigmoid(gpre) [B, mid]   We [mid, rd]

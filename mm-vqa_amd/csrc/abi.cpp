@@ -161,6 +161,11 @@ int mmvqa_se_dgate(mmvqa_stream_t s, const float* t, const float* z, const float
                    int N, int HW, int C) {
   return k_se_dgate(ST(s), t, z, sc, sh, dgate, N, HW, C);
 }
+int mmvqa_tap_thin_ok(long M, int N, int C, int HW) { return k_tap_thin_ok(M, N, C, HW) ? 1 : 0; }
+int mmvqa_tap_thin_fwd(mmvqa_stream_t s, const float* x, const float* sc, const float* sh, const float* W, float* out,
+                       long M, int N, int C, int HW, int act) {
+  return k_tap_thin_fwd(ST(s), x, sc, sh, W, out, M, N, C, HW, act);
+}
 int mmvqa_se_fc_fwd(mmvqa_stream_t s, const float* pool, const float* Wr, const float* br, const float* We,
                     const float* be, float* rpre, float* r, float* gpre, float* gate, int B, int mid, int rd) {
   int rc = k_skinny_fwd(ST(s), pool, mid, Wr, br, ACT_SILU, rpre, r, B, rd, mid);

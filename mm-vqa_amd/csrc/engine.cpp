@@ -667,6 +667,14 @@ static int tap_act(const mmvqa_engine* e) { return e->d.use_relu ? ACT_RELU : AC
 static int tap_fwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, const BNRef* bn_in) {
   REG(REG_TAP);
   const TapRef& t = e->taps[k];
+  static const bool thin_off = getenv("MMVQA_NO_TAP_THIN") != nullptr;   // A/B switch
+  if (!thin_off && k_tap_thin_ok(t.M, e->d.hidden, t.C, t.HW)) {
+    // few channels, huge map (the stem taps): weights stay in registers, no tile machinery (tapthin.hip)
+    RUN(PROF_OTHER, 0, k_tap_thin_fwd(st, fmap, bn_in ? WS(bn_in->scale) : nullptr, bn_in ? WS(bn_in->shift) : nullptr,
+                                      PRM(t.w), WS(e->vis) + (size_t)k * e->B * e->d.hidden, t.M, e->d.hidden, t.C, t.HW,
+                                      tap_act(e)));
+    return MMVQA_OK;
+  }
   GemmParams g = gp_linear_geom();
   g.M = (int)t.M; g.N = e->d.hidden; g.K = t.C;
   g.A = fmap; g.a_ld = t.C; g.g_Cs = t.C;
@@ -729,7 +737,16 @@ struct SideCtx {
   bool on;
   SideCtx(mmvqa_engine* e_, hipStream_t st_) : e(e_), st(st_) {
     on = e->use_side && !e->tuner.tuning;   // (the per-launch profiler records its events on the launching stream)
-    if (on && !e->side) on = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess;
+    if (on && !e->side) {
+      // the side stream carries work with slack (weight gradients, taps, downsample branches): lowest priority, so
+      // that the dependency chain on the caller's stream is dispatched first whenever both have kernels ready
+      int least = 0, greatest = 0;
+      static const bool prio_off = getenv("MMVQA_SIDE_PRIO_OFF") != nullptr;   // A/B switch
+      if (!prio_off && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+        on = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least) == hipSuccess;
+      else
+        on = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess;
+    }
     sd = on ? e->side : st;
   }
   hipEvent_t next_event() {

@@ -1536,8 +1536,9 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     hipEvent_t e0, e1;
     HIP_CHECK_RET(hipEventCreate(&e0));
     HIP_CHECK_RET(hipEventCreate(&e1));
-    float best = 1e30f;
-    Cand bc = cands[0];
+    float best = 1e30f, best_single = 1e30f;
+    Cand bc = cands[0], bc_single = cands[0];
+    const bool sk_partial = kind != KIND_WGRAD && sk_eligible(p, kind) && p.splitk <= 0;
     for (const Cand& c : cands) {
       GemmParams q = p;
       q.splitk = c.splitk;
@@ -1550,7 +1551,11 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
       float ms = 0.f;
       HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
       if (ms < best) { best = ms; bc = c; }
+      if (c.splitk <= 1 && ms < best_single) { best_single = ms; bc_single = c; }
     }
+    // K split with a finishing launch is timed here on an empty chip; inside the step it costs a second launch on the
+    // dependency chain and takes the CUs the other stream would use: only worth it when clearly faster
+    if (sk_partial && bc.splitk > 1 && best_single < 1e29f && best > 0.85f * best_single) { bc = bc_single; best = best_single; }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     it = g_tuner->table.emplace(key, std::make_pair(bc.tile, bc.splitk)).first;

@@ -79,6 +79,10 @@ int k_act_bwd_stats(hipStream_t st, const float* t, const float* gate, const flo
                     const float* s, const float* b, const float* mean, const float* invstd, int act, float* out,
                     double* stat, long npix, int HW, int C);
 int k_mul_dact(hipStream_t st, const float* x, const float* pre, int act, float* y, long n);
+// tapthin.hip: visual-token tap of a feature map with few channels (stem taps)
+bool k_tap_thin_ok(long M, int N, int C, int HW);
+int k_tap_thin_fwd(hipStream_t st, const float* x, const float* sc, const float* sh, const float* W, float* out, long M,
+                   int N, int C, int HW, int act);
 // se.hip: the squeeze-excite fully connected layers (16-row problems) without the GEMM tile machinery
 int k_skinny_fwd(hipStream_t st, const float* x, int x_ld, const float* W, const float* b, int act, float* pre,
                  float* y, int M, int N, int K);

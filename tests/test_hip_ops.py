@@ -865,3 +865,29 @@ def test_squeeze_excite_fc_layers(B, mid, rd):
     assert_close(dbe.cpu() - base[1], be.grad, TOL, "dbe")
     assert_close(dWr.cpu() - base[2], Wr.grad, TOL, "dWr")
     assert_close(dbr.cpu() - base[3], br.grad, TOL, "dbr")
+
+
+@pytest.mark.parametrize("C,pro,act", [(24, False, "serf"), (64, True, "serf"), (64, True, "relu"), (24, True, "serf")])
+def test_tap_thin_forward(C, pro, act):
+    """stem tap with few channels (conv1x1 C -> hidden, activation, global average pool; image_encoding.py:53-62) through
+    the register-resident kernel: vs plain torch, images whose pixel count is a multiple of 32 but not of the wave's run
+    of row tiles (image changes inside a wave), hidden sizes 768 and 100 (ragged last column group)"""
+    torch.manual_seed(C + (7 if pro else 0))
+    B, HW = 3, 12544
+    M = B * HW
+    for N in (768, 100):
+        assert L.lib().mmvqa_tap_thin_ok(M, N, C, HW) == 1
+        x = torch.randn(M, C)
+        W = torch.randn(N, C) / C ** 0.5
+        sc, sh = torch.rand(C) + 0.5, torch.randn(C) * 0.3
+        xin = torch.relu(x * sc + sh) if pro else x
+        u = xin @ W.t()
+        ref = (O.serf(u) if act == "serf" else torch.relu(u)).view(B, HW, N).mean(1)
+        xd, Wd, scd, shd = (t.contiguous().to(dev()) for t in (x, W, sc, sh))
+        out = torch.zeros(B, N, device=dev())
+        L.check(L.lib().mmvqa_tap_thin_fwd(L.stream_ptr(), P(xd), P(scd) if pro else None, P(shd) if pro else None, P(Wd),
+                                           P(out), M, N, C, HW, ACT(act)))
+        torch.cuda.synchronize()
+        assert_close(out, ref, TOL, f"tap_thin N={N}")
+    assert L.lib().mmvqa_tap_thin_ok(16 * 784, 768, 64, 784) == 0     # 784 pixels per image: not a multiple of 32
+    assert L.lib().mmvqa_tap_thin_ok(M, 768, 256, HW) == 0             # deep contraction: the GEMM kernel's job
