@@ -25,7 +25,8 @@ def build():
     os.makedirs(out, exist_ok=True)
     exp = os.environ.get("IGEMM_EXP", "")
     lib = os.path.join(out, "libmmvqa_trace%s.so" % exp.replace("-D", "_").replace(" ", ""))
-    srcs = [os.path.join(src, f) for f in ("igemm.hip", "attention.hip", "elementwise.hip", "engine.cpp", "abi.cpp")]
+    srcs = [os.path.join(src, f) for f in ("igemm.hip", "attention.hip", "elementwise.hip", "augment.hip", "se.hip", "tapthin.hip", "engine.cpp",
+                                           "abi.cpp")]
     if os.path.exists(lib) and all(os.path.getmtime(lib) > os.path.getmtime(s) for s in srcs):
         return lib
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
