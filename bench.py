@@ -45,15 +45,23 @@ PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 T
 B_PER_GPU, T, HW, VOCAB = 16, 32, 224, 30522
 
 
-CONFIG = 2   # BASELINE.json configs[1] (the metric's config); --config 3 = tf_efficientnetv2_m + realformer
+CONFIG = 2   # BASELINE.json configs[1] (the metric's config); --config 3 / 4 / 5 = configs[2] / [3] / [4] (tf_efficientnetv2_m
+             # + realformer: MLM bs16 | MLM + SupCon on 2N = 32 views | VQA fine-tune with ASLSingleLabel, bs64, T 28)
+N_CLASSES = 1552   # vqamed2019 answer classes (config 5)
 
 
 def make_args():
     from types import SimpleNamespace
-    if CONFIG == 3:
+    if CONFIG in (3, 4):
         return SimpleNamespace(task="MLM", dataset="roco", transformer_model="realformer",
                                cnn_encoder="tf_efficientnetv2_m", num_vis=5, hidden_size=768, n_layers=4, heads=12,
-                               hidden_dropout_prob=0.3, vocab_size=VOCAB, use_relu=False, max_position_embeddings=T)
+                               hidden_dropout_prob=0.3, vocab_size=VOCAB, use_relu=False, max_position_embeddings=T,
+                               supcon=(CONFIG == 4))
+    if CONFIG == 5:
+        return SimpleNamespace(task="VQA", dataset="VQA-Med", transformer_model="realformer",
+                               cnn_encoder="tf_efficientnetv2_m", num_vis=5, hidden_size=768, n_layers=4, heads=12,
+                               hidden_dropout_prob=0.3, vocab_size=N_CLASSES, emb_vocab=VOCAB, use_relu=False,
+                               max_position_embeddings=T)
     return SimpleNamespace(task="MLM", dataset="roco", transformer_model="transformer", cnn_encoder="resnet152",
                            num_vis=5, hidden_size=768, n_layers=4, heads=12, hidden_dropout_prob=0.3,
                            vocab_size=VOCAB, use_relu=False, max_position_embeddings=T)
@@ -159,10 +167,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3])
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
     a = ap.parse_args()
-    global CONFIG
+    global CONFIG, B_PER_GPU, T
     CONFIG = a.config
+    if CONFIG == 4:
+        B_PER_GPU = 32     # 2N = 32 views: 16 samples x 2 augmentations per GPU (pretrain/roco_supcon_train.py:137)
+    if CONFIG == 5:
+        B_PER_GPU, T = 64, 28
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -202,7 +214,16 @@ def main():
     red = GradReducer(model.flat_grads)
     if world > 1:
         model.set_grad_ready_hook(red.start)   # all-reduce of finished gradient ranges overlaps the backbone backward
-    img, ids, seg, mask, tgt = synth.roco_batch(B_PER_GPU, T, HW, VOCAB, seed=1234 + rank, device=dev)
+    if CONFIG == 4:
+        from mmvqa_amd import train as TR
+        va = synth.roco_batch(B_PER_GPU // 2, T, HW, VOCAB, seed=1234 + rank, device=dev)
+        vb = synth.roco_batch(B_PER_GPU // 2, T, HW, VOCAB, seed=4321 + rank, device=dev)
+        img, ids, seg, mask, tgt = TR.process_tensors((va[0], vb[0]), va[1], vb[1], va[2], va[3], va[4], vb[4])
+    elif CONFIG == 5:
+        from mmvqa_amd import train as TR
+        img, ids, seg, mask, tgt = synth.vqa_batch(B_PER_GPU, T, HW, VOCAB, N_CLASSES, seed=1234 + rank, device=dev)
+    else:
+        img, ids, seg, mask, tgt = synth.roco_batch(B_PER_GPU, T, HW, VOCAB, seed=1234 + rank, device=dev)
 
     marks = {}   # torch events around the launches that Python enqueues itself (loss kernels, Adam): same stream
 
@@ -215,6 +236,12 @@ def main():
                 e.record()
                 marks[name] = e
 
+        if CONFIG == 4:    # MLM on both views + SupCon over the (all-gathered) view set: mm-vqa_amd/train.py
+            loss, _, stats = TR.supcon_step(model, opt, red, world, (img, ids, seg, mask, tgt))
+            return [loss.detach()]
+        if CONFIG == 5:    # VQA head + ASLSingleLabel
+            loss, _ = TR.vqa_step(model, opt, red, world, (img, ids, seg, mask, tgt), mmvqa_amd.asl_loss)
+            return [loss.detach()]
         logits = model(img, ids, seg, mask)
         mark("loss_fwd_a")
         loss, _, stats = mmvqa_amd.mlm_loss(logits, tgt)
@@ -287,22 +314,32 @@ def main():
                                        avg_launch_us=gs["ms"] * 1e3 / max(1, gs["launches"]),
                                        note="same step with the second HIP stream disabled: no launch shares the chip"),
                     other_ms_per_step=dict(attention=pr["attention"]["ms"], elementwise=pr["other"]["ms"]))
-        roof["blocks"] = per_block(regs, marks, model, a)
+        if CONFIG in (2, 3):
+            roof["blocks"] = per_block(regs, marks, model, a)
 
-    wl = ("pretrain/roco_train.py MLM-only: resnet152 + transformer(4 layers, 12 heads), " if CONFIG == 2 else
-          "pretrain/roco_train.py MLM-only: tf_efficientnetv2_m + realformer(4 layers, 8 heads), ")
-    out = dict(metric="samples/sec ROCO-MLM pretrain (resnet152+transformer, bs16/GPU, 224^2, seq32)" if CONFIG == 2 else
-               "samples/sec ROCO-MLM pretrain (tf_efficientnetv2_m+realformer, bs16/GPU, 224^2, seq32)",
-               value=value, unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=ms,
-               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload=wl + "num_vis 5, hidden 768, vocab 30522, per-GPU batch 16, 224x224, T=32; "
-                                    "fwd + log_softmax/NLL + bwd + grad all-reduce + Adam; dropout on, train-mode BN; "
-                                    "random-init weights",
+    names = {2: ("ROCO-MLM pretrain (resnet152+transformer, bs16/GPU, 224^2, seq32)",
+                 "pretrain/roco_train.py MLM-only: resnet152 + transformer(4 layers, 12 heads), num_vis 5, hidden 768, vocab "
+                 "30522, per-GPU batch 16, 224x224, T=32; fwd + log_softmax/NLL + bwd + grad all-reduce + Adam"),
+             3: ("ROCO-MLM pretrain (tf_efficientnetv2_m+realformer, bs16/GPU, 224^2, seq32)",
+                 "pretrain/roco_train.py MLM-only: tf_efficientnetv2_m + realformer(4 layers, 8 heads), num_vis 5, hidden 768, "
+                 "vocab 30522, per-GPU batch 16, 224x224, T=32; fwd + log_softmax/NLL + bwd + grad all-reduce + Adam"),
+             4: ("ROCO MLM+SupCon pretrain (tf_efficientnetv2_m+realformer, 2N=32 views/GPU, 224^2, seq32)",
+                 "pretrain/roco_supcon_train.py --con_task=supcon: tf_efficientnetv2_m + realformer + SupCon head, 16 samples x 2 "
+                 "views per GPU, 224x224, T=32; fwd + MLM loss + all-gather of the views + SupCon loss + bwd + grad "
+                 "all-reduce + Adam"),
+             5: ("VQA-Med-2019 fine-tune (tf_efficientnetv2_m+realformer, ASLSingleLabel, bs64/GPU, 224^2, seq28)",
+                 "vqamed2019/train.py --loss=ASLSingleLabel: tf_efficientnetv2_m + realformer, VQA head with 1552 classes, "
+                 "per-GPU batch 64, 224x224, T=28; fwd + ASL + bwd + grad all-reduce + Adam")}
+    metric, wl = names[CONFIG]
+    last = stats[0]
+    out = dict(metric="samples/sec " + metric, value=value, unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+               ms_per_step=ms, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=wl + "; dropout on, train-mode BN; random-init weights",
                            global_batch=B_PER_GPU * world, seq_len=T, parallelism=f"dp{world}",
-                           samples_per_s_per_gpu=value / world, final_loss=float(stats[0])))
+                           samples_per_s_per_gpu=value / world, final_loss=float(last.detach() if hasattr(last, "detach") else last)))
     if roof is not None:
         out["roofline"] = roof
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and CONFIG == 2:
         out["cpu_baseline"] = cpu_baseline(1234)
     if rank == 0:
         print(json.dumps(out), flush=True)
