@@ -202,6 +202,77 @@ def test_full_config5_effnetv2m_realformer_vqa_asl():
                          rf_dropout_prob=0.0), B=2, T=28, hw=128, kind="vqa", stat_tol=TOL)
 
 
+@pytest.mark.parametrize("cfg", ["config2", "config3", "config5"])
+def test_tuned_launch_choices_give_the_same_step(cfg):
+    """bench.py / train.py call Model.tune(): every GEMM shape of the step then runs with the tile, split-K factor and
+    (for products with few output tiles) the K split over workgroups + finishing launch the timed tuner picked -- other
+    kernels than the untuned defaults the parity tests above go through.  Full width, 224x224 and the bench's batch, so
+    that every GEMM shape of the full models occurs; two blocks per ResNet layer / a quarter of the EfficientNet
+    repeats keep the chaotic amplification of fp32 reordering noise through 150 train-mode BatchNorms out of the
+    comparison.  The tuned step must give the logits, loss and every gradient of the untuned one (same arithmetic,
+    another summation order), and tuning itself must leave parameters, buffers and gradients untouched."""
+    if cfg == "config2":
+        args = O.make_args(resnet_layers=(2, 2, 2, 2), hidden_dropout_prob=0.0, emb_dropout_prob=0.0, rf_dropout_prob=0.0)
+        B, T, kind = 16, 32, "mlm"
+    elif cfg == "config3":
+        args = O.make_args(cnn_encoder="tf_efficientnetv2_m", effnet_depth_div=4, transformer_model="realformer", heads=8,
+                           supcon=True, hidden_dropout_prob=0.0, emb_dropout_prob=0.0, rf_dropout_prob=0.0)
+        B, T, kind = 16, 32, "supcon"
+    else:
+        args = O.make_args(cnn_encoder="tf_efficientnetv2_m", effnet_depth_div=4, transformer_model="realformer", heads=8,
+                           dataset="VQA-Med", vocab_size=1552, emb_vocab=30522, hidden_dropout_prob=0.0,
+                           emb_dropout_prob=0.0, rf_dropout_prob=0.0)
+        B, T, kind = 32, 28, "vqa"
+    torch.manual_seed(3)
+    hip = mmvqa_amd.Model(args)
+    hip.to(dev()).train()
+    if kind == "vqa":
+        batch = synth.vqa_batch(B, T, 224, vocab=30522, n_classes=1552, seed=9, device=dev())
+    else:
+        batch = synth.roco_batch(B, T, 224, vocab=30522, seed=9, device=dev(), mlm_prob=0.3)
+    img, ids, seg, mask, tgt = batch
+
+    def step():
+        hip.flat_grads.zero_()
+        out = hip(img, ids, seg, mask)
+        if kind == "vqa":
+            logits = out[0]
+            loss = mmvqa_amd.asl_loss(logits, tgt)
+        elif kind == "supcon":
+            logits = out[0]
+            loss = mmvqa_amd.mlm_loss(logits, tgt)[0] + mmvqa_amd.supcon_loss(mmvqa_amd.split_feat(out[1], B // 2))
+        else:
+            logits = out
+            loss = mmvqa_amd.mlm_loss(logits, tgt)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), float(loss), hip.flat_grads.detach().clone()
+
+    l0, loss0, g0 = step()
+    p_before, b_before = hip.flat_params.detach().clone(), hip._flat[1].clone()
+    n = hip.tune(img, ids, seg, mask)
+    assert n > 20, n
+    assert torch.equal(hip.flat_params, p_before) and torch.equal(hip._flat[1], b_before)
+    assert float(hip.flat_grads.abs().max()) == 0.0
+    l1, loss1, g1 = step()
+    assert relerr(l1, l0) <= 1e-4, f"logits tuned vs untuned {relerr(l1, l0):.2e}"
+    assert abs(loss1 - loss0) <= 5e-4 * abs(loss0), (loss1, loss0)
+    # per parameter tensor, relative to that tensor's largest gradient -- floored at 1e-3 of the largest gradient of the
+    # model: a bias in front of a BatchNorm (projection-BN beta, proj_k.bias) has an exact gradient of zero and what
+    # either run computes for it is rounding noise
+    worst = ("", 0.0)
+    floor = 1e-3 * float(g0.abs().max())
+    for name, prm in hip.named_parameters():
+        o, k = prm.data_ptr() - hip.flat_params.data_ptr(), prm.numel()
+        a, b = g1[o // 4:o // 4 + k], g0[o // 4:o // 4 + k]
+        scale = max(float(b.abs().max()), floor)
+        e = float((a - b).abs().max()) / scale
+        if e > worst[1]:
+            worst = (name, e)
+    assert worst[1] <= 2e-2, f"gradient tuned vs untuned: {worst}"
+    assert relerr(g1, g0) <= 1e-3, f"all gradients tuned vs untuned {relerr(g1, g0):.2e}"
+
+
 @pytest.mark.parametrize("tag,tm,ds,supcon,cnn,relu", MODEL_CASES)
 def test_golden_reference_replay(golden_dir, tag, tm, ds, supcon, cnn, relu):
     """inputs/outputs recorded from the REFERENCE's own Model.forward (tests/golden/make_golden.py), incl. its
