@@ -247,6 +247,9 @@ int mmvqa_se_dgate(mmvqa_stream_t s, const float* t, const float* z, const float
 int mmvqa_tap_thin_ok(long M, int N, int C, int HW);
 int mmvqa_tap_thin_fwd(mmvqa_stream_t s, const float* x, const float* sc, const float* sh, const float* W, float* out,
                        long M, int N, int C, int HW, int act);
+/* backward recompute of the same tap: du[pix][n] = dv[img][n] / HW * act'(sum_c x'[pix][c] W[n][c]); du [M, N] */
+int mmvqa_tap_thin_bwd(mmvqa_stream_t s, const float* x, const float* sc, const float* sh, const float* W,
+                       const float* dv, float* du, long M, int N, int C, int HW, int act);
 /* squeeze-excite fully connected layers (timm SqueezeExcite conv_reduce / conv_expand on the pooled [B, mid] tensor):
  *   rpre = pool Wr^T + br, r = silu(rpre)   [B, rd]   Wr [rd, mid]
  *   gpre = r We^T + be,    gate = sigmoid(gpre) [B, mid]   We [mid, rd]

@@ -114,6 +114,7 @@ SIGNATURES = {
     "mmvqa_se_dgate": (_i, [_P, _P, _P, _P, _P, _P, _i, _i, _i]),
     "mmvqa_tap_thin_ok": (_i, [_l, _i, _i, _i]),
     "mmvqa_tap_thin_fwd": (_i, [_P] * 6 + [_l, _i, _i, _i, _i]),
+    "mmvqa_tap_thin_bwd": (_i, [_P] * 7 + [_l, _i, _i, _i, _i]),
     "mmvqa_se_fc_fwd": (_i, [_P] * 10 + [_i, _i, _i]),
     "mmvqa_se_fc_bwd_scratch_floats": (_sz, [_i, _i, _i]),
     "mmvqa_se_fc_bwd": (_i, [_P] * 14 + [_i, _i, _i]),

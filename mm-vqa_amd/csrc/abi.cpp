@@ -166,6 +166,10 @@ int mmvqa_tap_thin_fwd(mmvqa_stream_t s, const float* x, const float* sc, const 
                        long M, int N, int C, int HW, int act) {
   return k_tap_thin_fwd(ST(s), x, sc, sh, W, out, M, N, C, HW, act);
 }
+int mmvqa_tap_thin_bwd(mmvqa_stream_t s, const float* x, const float* sc, const float* sh, const float* W,
+                       const float* dv, float* du, long M, int N, int C, int HW, int act) {
+  return k_tap_thin_bwd(ST(s), x, sc, sh, W, dv, du, M, N, C, HW, act);
+}
 int mmvqa_se_fc_fwd(mmvqa_stream_t s, const float* pool, const float* Wr, const float* br, const float* We,
                     const float* be, float* rpre, float* r, float* gpre, float* gate, int B, int mid, int rd) {
   int rc = k_skinny_fwd(ST(s), pool, mid, Wr, br, ACT_SILU, rpre, r, B, rd, mid);

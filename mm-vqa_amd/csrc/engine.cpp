@@ -668,8 +668,9 @@ static int tap_fwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, co
   REG(REG_TAP);
   const TapRef& t = e->taps[k];
   static const bool thin_off = getenv("MMVQA_NO_TAP_THIN") != nullptr;   // A/B switch
-  if (!thin_off && k_tap_thin_ok(t.M, e->d.hidden, t.C, t.HW)) {
-    // few channels, huge map (the stem taps): weights stay in registers, no tile machinery (tapthin.hip)
+  // (C = 64 with BatchNorm+ReLU on load needs 256 VGPRs there and only ties the GEMM kernel: measured, round 2)
+  if (!thin_off && t.C <= 32 && k_tap_thin_ok(t.M, e->d.hidden, t.C, t.HW)) {
+    // few channels, huge map (EfficientNet's stem tap): weights stay in registers, no tile machinery (tapthin.hip)
     RUN(PROF_OTHER, 0, k_tap_thin_fwd(st, fmap, bn_in ? WS(bn_in->scale) : nullptr, bn_in ? WS(bn_in->shift) : nullptr,
                                       PRM(t.w), WS(e->vis) + (size_t)k * e->B * e->d.hidden, t.M, e->d.hidden, t.C, t.HW,
                                       tap_act(e)));
@@ -703,7 +704,12 @@ static int tap_bwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, co
   g.tap_dv = WS(e->dvis) + (size_t)k * e->B * Hd;
   g.C = WS(e->du); g.c_ld = Hd;
   set_sk(e, st, g);
-  RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
+  static const bool thin_off = getenv("MMVQA_NO_TAP_THIN") != nullptr;
+  if (!thin_off && t.C <= 32 && k_tap_thin_ok(t.M, Hd, t.C, t.HW))   // EfficientNet stem tap: recompute in registers (tapthin.hip)
+    RUN(PROF_OTHER, 0, k_tap_thin_bwd(st, fmap, bn_in ? WS(bn_in->scale) : nullptr, bn_in ? WS(bn_in->shift) : nullptr,
+                                      PRM(t.w), g.tap_dv, WS(e->du), t.M, Hd, t.C, t.HW, tap_act(e)));
+  else
+    RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
   // dW_tap[Hd][C] += du^T fmap
   GemmParams w = gp_linear_geom();
   w.M = Hd; w.N = t.C; w.K = (int)t.M;

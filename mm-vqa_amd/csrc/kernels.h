@@ -83,6 +83,8 @@ int k_mul_dact(hipStream_t st, const float* x, const float* pre, int act, float*
 bool k_tap_thin_ok(long M, int N, int C, int HW);
 int k_tap_thin_fwd(hipStream_t st, const float* x, const float* sc, const float* sh, const float* W, float* out, long M,
                    int N, int C, int HW, int act);
+int k_tap_thin_bwd(hipStream_t st, const float* x, const float* sc, const float* sh, const float* W, const float* dv,
+                   float* du, long M, int N, int C, int HW, int act);
 // se.hip: the squeeze-excite fully connected layers (16-row problems) without the GEMM tile machinery
 int k_skinny_fwd(hipStream_t st, const float* x, int x_ld, const float* W, const float* b, int act, float* pre,
                  float* y, int M, int N, int K);

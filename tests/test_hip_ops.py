@@ -889,5 +889,15 @@ def test_tap_thin_forward(C, pro, act):
                                            P(out), M, N, C, HW, ACT(act)))
         torch.cuda.synchronize()
         assert_close(out, ref, TOL, f"tap_thin N={N}")
+        # backward recompute: du = dv[img] / HW * act'(u)
+        dv = torch.randn(B, N)
+        uu = u.clone().requires_grad_(True)
+        (O.serf(uu) if act == "serf" else torch.relu(uu)).view(B, HW, N).mean(1).backward(dv)
+        du = torch.full((M, N), float("nan"), device=dev())
+        dvd = dv.to(dev())
+        L.check(L.lib().mmvqa_tap_thin_bwd(L.stream_ptr(), P(xd), P(scd) if pro else None, P(shd) if pro else None, P(Wd),
+                                           P(dvd), P(du), M, N, C, HW, ACT(act)))
+        torch.cuda.synchronize()
+        assert_close(du, uu.grad, TOL, f"tap_thin du N={N}")
     assert L.lib().mmvqa_tap_thin_ok(16 * 784, 768, 64, 784) == 0     # 784 pixels per image: not a multiple of 32
     assert L.lib().mmvqa_tap_thin_ok(M, 768, 256, HW) == 0             # deep contraction: the GEMM kernel's job
