@@ -38,6 +38,9 @@ struct GemmAux {
   int fast;   // 0: general loaders | 1: uniform-tap loaders | 2: uniform-tap loaders with a halo mask (host-decided)
   int stagger;   // 8-wave variant: the second wave group runs its VALU/LDS-write block first (0 = off, for A/B timing)
   float* part;   // split-K over workgroups with a finishing launch: partial tiles [split][M][N] go here, no epilogue
+  int xcd;       // workgroup ids are dealt round-robin to the 8 XCDs: renumber so that an XCD gets a CONTIGUOUS run of
+                 // tiles (1: the N-tiles of an M-panel, 2: the M-tiles of an N-panel share that XCD's L2 instead of
+                 // pulling the panel into up to 8 of them)
 };
 
 __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
@@ -314,7 +317,26 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
   const int lane = tid & 63, wave = (tid >> 6) & 3, ks = tid >> 8;
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (x.xcd) {
+    // hardware id L goes to XCD L % 8; logical id Lg: XCD j owns the run [j*per, (j+1)*per), the < 8 ids past 8*per keep
+    // their number.  xcd == 1: N-tiles of an M-panel are consecutive (they share operand A); 2: M-tiles of an N-panel are
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned L = bx + gx * (by + gy * bz), per = (gx * gy * gridDim.z) >> 3;
+    const unsigned Lg = L < 8u * per ? (L & 7u) * per + (L >> 3) : L;
+    if (x.xcd == 1) {
+      bx = (int)(Lg % gx);
+      const unsigned r = Lg / gx;
+      by = (int)(r % gy);
+      bz = (int)(r / gy);
+    } else {
+      by = (int)(Lg % gy);
+      const unsigned r = Lg / gy;
+      bx = (int)(r % gx);
+      bz = (int)(r / gx);
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
 #ifdef EXP_SAMETILE   // experiment: every workgroup loads the tiles of workgroup (0,0) -> all loads hit in L2
   const int lm0 = 0, ln0 = 0;
 #else
@@ -323,7 +345,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
 
   // K range of this split
   const int nkt_total = (p.K + BK - 1) / BK;
-  const int kt_begin = blockIdx.z * p.ktiles_per_split;
+  const int kt_begin = bz * p.ktiles_per_split;
   int kt_end = kt_begin + p.ktiles_per_split;
   if (kt_end > nkt_total) kt_end = nkt_total;
   const int nkt = kt_end - kt_begin;
@@ -1228,7 +1250,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
 
   if (x.part) {
     // split-K over workgroups, finished by splitk_finish_kernel: this workgroup's partial tile, row-wise 16-byte stores
-    float* P = x.part + (size_t)blockIdx.z * M * N;
+    float* P = x.part + (size_t)bz * M * N;
 #pragma unroll 1
     for (int ps = 0; ps < NPASS; ++ps) {
       const int rl = rg + ps * RP, row = m0 + rl;
@@ -1427,6 +1449,17 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
     }
   }
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splitk);
+  static const int xcd_on = getenv("MMVQA_IGEMM_NOXCD") ? 0 : 1;   // A/B switch
+  const long nwg = (long)grid.x * grid.y * grid.z;
+  x.xcd = 0;
+  if (xcd_on && nwg >= 32 && !NCHW) {
+    // bytes behind the row panels (A side) and the column panels (B side): keep the larger one XCD-local
+    double a_bytes, b_bytes;
+    if (KIND == KIND_WGRAD) { a_bytes = (double)p.K * p.M * (p.a_pro == PRO_DZ ? 2 : 1); b_bytes = (double)p.K * p.g_Cs; }
+    else if (KIND == KIND_FWD) { a_bytes = (double)p.M * p.g_stride * p.g_stride * p.g_Cs; b_bytes = (double)p.N * p.K; }
+    else { a_bytes = (double)p.M * p.g_Cs * (p.a_pro == PRO_DZ ? 2 : 1); b_bytes = (double)p.N * p.K; }
+    x.xcd = (b_bytes > a_bytes && grid.y > 1) ? 2 : (grid.x > 1 ? 1 : 0);
+  }
   if (getenv("MMVQA_IGEMM_LOG"))   // one line per launch: which loader family a shape gets (diagnostics)
     fprintf(stderr, "igemm kind %d fast %d tile %dx%dx%d ks %d M %d N %d K %d Cs %d taps %d stride %d apro %d bpro %d splitk %d\n", KIND, x.fast,
             BM, BN, BK, KS, p.M, p.N, p.K, p.g_Cs, p.g_KH * p.g_KW, p.g_stride, p.a_pro, p.b_pro, p.splitk);
