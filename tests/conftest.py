@@ -8,8 +8,30 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def host_threads():
+    """threads this process may really use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
+    whole host; an intra-op pool of that size under a 16-CPU quota makes the CPU oracle several times slower)"""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(host_threads(), 32)))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -80,6 +80,14 @@ def compare_grads(orc, hip, orc64=None, tol=TOL):
     assert not bad, "gradient mismatches: " + ", ".join(f"{n} {e:.2e} (tol {t:.1e})" for n, e, t in bad[:12])
 
 
+def oracle_loss(kind, out, tgt, B):
+    if kind == "vqa":
+        return O.asl_single_label(out[0], tgt)
+    if kind == "supcon":
+        return O.mlm_loss(out[0], tgt)[0] + O.supcon_simclr(O.split_feat(out[1], B // 2))
+    return O.mlm_loss(out, tgt)[0]
+
+
 def run_case(args, B, T, hw, kind, seed=0, stat_tol=1e-4):
     orc, hip = build_pair(args, seed)
     V = args.vocab_size
@@ -92,31 +100,25 @@ def run_case(args, B, T, hw, kind, seed=0, stat_tol=1e-4):
     orc.train()
     hip.train()
     out_ref = orc(img, ids, seg, mask)
-    out64 = orc64(img.double(), ids, seg, mask)
     out = hip(img.to(dev()), ids.to(dev()), seg.to(dev()), mask.to(dev()))
+    loss_ref = oracle_loss(kind, out_ref, tgt, B)
     if kind == "vqa":
         assert out[1] == 0 and out[2] == 0
         logits, logits_ref = out[0], out_ref[0]
-        loss_ref = O.asl_single_label(logits_ref, tgt)
-        loss64 = O.asl_single_label(out64[0], tgt)
         loss = mmvqa_amd.asl_loss(logits, tgt.to(dev()))
     elif kind == "supcon":
         logits, feat = out
         logits_ref, feat_ref = out_ref
         assert relerr(feat, feat_ref) <= TOL, f"feat {relerr(feat, feat_ref):.2e}"
-        loss_ref = O.mlm_loss(logits_ref, tgt)[0] + O.supcon_simclr(O.split_feat(feat_ref, B // 2))
-        loss64 = O.mlm_loss(out64[0], tgt)[0] + O.supcon_simclr(O.split_feat(out64[1], B // 2))
         loss = mmvqa_amd.mlm_loss(logits, tgt.to(dev()))[0] + mmvqa_amd.supcon_loss(mmvqa_amd.split_feat(feat, B // 2))
     else:
         logits, logits_ref = out, out_ref
-        loss_ref = O.mlm_loss(logits_ref, tgt)[0]
-        loss64 = O.mlm_loss(out64, tgt)[0]
         loss = mmvqa_amd.mlm_loss(logits, tgt.to(dev()))[0]
     e = relerr(logits, logits_ref)
     assert e <= TOL, f"logits rel err {e:.2e}"
     assert abs(float(loss) - float(loss_ref)) <= TOL * abs(float(loss_ref)), (float(loss), float(loss_ref))
     loss_ref.backward()
-    loss64.backward()
+    oracle_loss(kind, orc64(img.double(), ids, seg, mask), tgt, B).backward()
     loss.backward()
     compare_grads(orc, hip, orc64)
     # BatchNorm running statistics incl. the k-fold update rule (quirk 7)
@@ -187,19 +189,26 @@ def test_full_config3_and_4_effnetv2m_realformer_mlm_supcon_224():
     vocab 30522 -- configs[2] is pretrain/roco_train.py (MLM head), configs[3] is pretrain/roco_supcon_train.py, the same
     model with the SupCon head added on 2N views (two crops per sample concatenated along the batch): one run checks
     the MLM logits and loss of both, feat, the SupCon loss, every gradient and the BatchNorm buffers against the fp32 /
-    fp64 oracle (2N = 4 keeps the CPU oracle to about a minute and a half)"""
+    fp64 oracle (2N = 8 views)"""
     run_case(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer", heads=8, supcon=True,
-                         hidden_dropout_prob=0.0, emb_dropout_prob=0.0, rf_dropout_prob=0.0), B=4, T=32, hw=224,
+                         hidden_dropout_prob=0.0, emb_dropout_prob=0.0, rf_dropout_prob=0.0), B=8, T=32, hw=224,
              kind="supcon", stat_tol=TOL)
 
 
-def test_full_config5_effnetv2m_realformer_vqa_asl():
+def test_full_config5_effnetv2m_realformer_vqa_asl_224():
     """BASELINE.json configs[4]: vqamed2019/train.py --loss=ASLSingleLabel, tf_efficientnetv2_m + RealFormer, VQA head
-    (masked mean-pool) with 1552 answer classes, T 28 (the script's default), full depth and width, batch 2; 128x128
-    images (the 224x224 backbone is the test above; this one is about the VQA head, ASL and T = 28 at full width)"""
+    (masked mean-pool) with 1552 answer classes, T 28 (the script's default), full depth and width, 224x224, batch 4"""
     run_case(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer", heads=8, dataset="VQA-Med",
                          vocab_size=1552, emb_vocab=30522, hidden_dropout_prob=0.0, emb_dropout_prob=0.0,
-                         rf_dropout_prob=0.0), B=2, T=28, hw=128, kind="vqa", stat_tol=TOL)
+                         rf_dropout_prob=0.0), B=4, T=28, hw=224, kind="vqa", stat_tol=TOL)
+
+
+def test_full_config5_one_image_batch():
+    """the smallest batch the path accepts, full depth and width: batch statistics over the pixels of a single 128x128
+    image, squeeze-excite and ASL on one row"""
+    run_case(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer", heads=8, dataset="VQA-Med",
+                         vocab_size=1552, emb_vocab=30522, hidden_dropout_prob=0.0, emb_dropout_prob=0.0,
+                         rf_dropout_prob=0.0), B=1, T=28, hw=128, kind="vqa", stat_tol=TOL)
 
 
 @pytest.mark.parametrize("cfg", ["config2", "config3", "config5"])
@@ -269,7 +278,9 @@ def test_tuned_launch_choices_give_the_same_step(cfg):
         e = float((a - b).abs().max()) / scale
         if e > worst[1]:
             worst = (name, e)
-    assert worst[1] <= 2e-2, f"gradient tuned vs untuned: {worst}"
+    # (a wrong tile / split variant shows up as an O(1) error of the tensors it touches; the reordering noise of fp32
+    # sums through train-mode BatchNorms at random init reaches about 2e-2 of a tensor's largest gradient)
+    assert worst[1] <= 5e-2, f"gradient tuned vs untuned: {worst}"
     assert relerr(g1, g0) <= 1e-3, f"all gradients tuned vs untuned {relerr(g1, g0):.2e}"
 
 
