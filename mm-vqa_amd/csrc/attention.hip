@@ -49,6 +49,26 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnParams p) {
   }
   const float qmask = (qvalid && p.mask_on_query) ? (float)p.mask[b * T + qi] : 1.f;
 
+  // One 32-key tile (T <= 32, the bench's shape): every global load of the kernel is issued here, before the first
+  // store.  The stores below (prev_out, probs, out) may alias the inputs as far as the compiler knows, so loads placed
+  // after them each waited for a full memory round trip: 20 us for 64 MFMAs of work (round-2 profile).
+  constexpr bool HOIST = (NJ == 1);
+  float h_mk[HOIST ? 16 : 1], h_pv[HOIST ? 16 : 1], h_v[HOIST ? ND * 16 : 1];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int j = erow(e, lh);
+      const bool ok = j < T && qvalid;
+      h_mk[e] = (ok && !p.mask_on_query) ? (float)p.mask[b * T + j] : 1.f;
+      h_pv[e] = (ok && p.prev_in) ? p.prev_in[((size_t)(b * T + qi) * T + j) * p.heads + head] : 0.f;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        const int dd = dt * 32 + li;
+        h_v[dt * 16 + e] = (j < T && dd < D) ? p.v[(size_t)(b * T + j) * p.row_stride + hb + dd] : 0.f;
+      }
+    }
+  }
+
   f32x16 sc[NJ];
 #pragma unroll
   for (int jt = 0; jt < NJ; ++jt) {
@@ -78,8 +98,14 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnParams p) {
       if (j < T && qvalid) {
         s = sc[jt][e] / p.sqrt_d;
         const size_t po = ((size_t)(b * T + qi) * T + j) * p.heads + head;
-        if (p.prev_in) s = s + p.prev_in[po];
-        float mval = p.mask_on_query ? qmask : (float)p.mask[b * T + j];
+        float mval;
+        if constexpr (HOIST) {
+          if (p.prev_in) s = s + h_pv[e];
+          mval = p.mask_on_query ? qmask : h_mk[e];
+        } else {
+          if (p.prev_in) s = s + p.prev_in[po];
+          mval = p.mask_on_query ? qmask : (float)p.mask[b * T + j];
+        }
         s = s - 10000.0f * (1.0f - mval);
         if (p.prev_out) p.prev_out[po] = s;
       }
@@ -128,7 +154,9 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int j = jt * 32 + erow(e, lh);
-        float vv = (j < T && dd < D) ? p.v[(size_t)(b * T + j) * p.row_stride + hb + dd] : 0.f;
+        float vv;
+        if constexpr (HOIST) vv = h_v[dt * 16 + e];
+        else vv = (j < T && dd < D) ? p.v[(size_t)(b * T + j) * p.row_stride + hb + dd] : 0.f;
         o = __builtin_amdgcn_mfma_f32_32x32x2f32(sc[jt][e], vv, o, 0, 0, 0);
       }
     }
@@ -157,6 +185,31 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnParams p) {
   const size_t pbase = (size_t)(b * p.heads + head) * T * T;
 
   float delta[NJ];  // delta[it] for query it*32+li
+  // One 32 x 32 tile (T <= 32): every global load of both passes is issued here, before the first store (see the
+  // forward kernel: the dq / dprev stores would otherwise fence the loads of pass B behind them, one round trip each)
+  constexpr bool HOIST = (NJ == 1);
+  float h_pa[HOIST ? 16 : 1], h_pb[HOIST ? 16 : 1], h_da[HOIST ? 16 : 1], h_db[HOIST ? 16 : 1];
+  float h_k[HOIST ? ND * 16 : 1], h_q[HOIST ? ND * 16 : 1], h_do[HOIST ? ND * 16 : 1];
+  if constexpr (HOIST) {
+    const bool lv = li < T;   // this lane's query (pass A) / key (pass B) exists
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = erow(e, lh);   // the key of pass A, the query of pass B
+      const bool ok = r < T && lv;
+      h_pa[e] = ok ? p.probs[pbase + (size_t)r * T + li] : 0.f;
+      h_pb[e] = ok ? p.probs[pbase + (size_t)li * T + r] : 0.f;
+      h_da[e] = (ok && p.dprev_in) ? p.dprev_in[((size_t)(b * T + li) * T + r) * p.heads + head] : 0.f;
+      h_db[e] = (ok && p.dprev_in) ? p.dprev_in[((size_t)(b * T + r) * T + li) * p.heads + head] : 0.f;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        const int dd = dt * 32 + li;
+        const bool okd = r < T && dd < D;
+        h_k[dt * 16 + e] = okd ? p.k[(size_t)(b * T + r) * p.row_stride + hb + dd] : 0.f;
+        h_q[dt * 16 + e] = okd ? p.q[(size_t)(b * T + r) * p.row_stride + hb + dd] : 0.f;
+        h_do[dt * 16 + e] = okd ? p.dout[(size_t)(b * T + r) * p.out_row_stride + ohb + dd] : 0.f;
+      }
+    }
+  }
   // ------------------------------ pass A
 #pragma unroll
   for (int it = 0; it < NJ; ++it) {
@@ -190,7 +243,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnParams p) {
         const int j = jt * 32 + erow(e, lh);
         float pr = 0.f, dp = 0.f;
         if (j < T && qvalid) {
-          pr = p.probs[pbase + (size_t)j * T + qi];
+          if constexpr (HOIST) pr = h_pa[e];
+          else pr = p.probs[pbase + (size_t)j * T + qi];
           dp = a[e];
           if (p.drop_p > 0.f) {
             float u = rng_uniform(p.seed, (uint32_t)(((b * p.heads + head) * T + qi) * T + j));
@@ -216,10 +270,13 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnParams p) {
         const int j = jt * 32 + erow(e, lh);
         float g = 0.f;
         if (j < T && qvalid) {
-          float pr = p.probs[pbase + (size_t)j * T + qi];
+          float pr;
+          if constexpr (HOIST) pr = h_pa[e];
+          else pr = p.probs[pbase + (size_t)j * T + qi];
           g = ds[jt][e] - pr * dl;
           const size_t po = ((size_t)(b * T + qi) * T + j) * p.heads + head;
-          if (p.dprev_in) g += p.dprev_in[po];
+          if constexpr (HOIST) { if (p.dprev_in) g += h_da[e]; }
+          else { if (p.dprev_in) g += p.dprev_in[po]; }
           if (p.dprev_out) p.dprev_out[po] = g;
           g = g / p.sqrt_d;
         }
@@ -231,7 +288,9 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int j = jt * 32 + erow(e, lh);
-          float kv = (j < T && dd < D) ? p.k[(size_t)(b * T + j) * p.row_stride + hb + dd] : 0.f;
+          float kv;
+          if constexpr (HOIST) kv = h_k[dt * 16 + e];
+          else kv = (j < T && dd < D) ? p.k[(size_t)(b * T + j) * p.row_stride + hb + dd] : 0.f;
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[jt][e], kv, dq[dt], 0, 0, 0);
         }
       }
@@ -285,7 +344,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnParams p) {
         const float dli = __shfl(delta[it], erow(e, lh), 64);  // delta of query i lives in lane (i & 31)
         float pr = 0.f, prd = 0.f, g = 0.f;
         if (i < T && kvalid) {
-          pr = p.probs[pbase + (size_t)kj * T + i];
+          if constexpr (HOIST) pr = h_pb[e];
+          else pr = p.probs[pbase + (size_t)kj * T + i];
           float dp = a[e];
           prd = pr;
           if (p.drop_p > 0.f) {
@@ -295,7 +355,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnParams p) {
             prd = keep ? pr * ks : 0.f;
           }
           g = pr * (dp - dli);
-          if (p.dprev_in) g += p.dprev_in[((size_t)(b * T + i) * T + kj) * p.heads + head];
+          if constexpr (HOIST) { if (p.dprev_in) g += h_db[e]; }
+          else { if (p.dprev_in) g += p.dprev_in[((size_t)(b * T + i) * T + kj) * p.heads + head]; }
           g = g / p.sqrt_d;
         }
         pd[e] = prd; sd[e] = g;
@@ -308,8 +369,12 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnParams p) {
         for (int e = 0; e < 16; ++e) {
           const int i = it * 32 + erow(e, lh);
           const bool ok = (i < T && dd < D);
-          float qv = ok ? p.q[(size_t)(b * T + i) * p.row_stride + hb + dd] : 0.f;
-          float dov = ok ? p.dout[(size_t)(b * T + i) * p.out_row_stride + ohb + dd] : 0.f;
+          float qv, dov;
+          if constexpr (HOIST) { qv = h_q[dt * 16 + e]; dov = h_do[dt * 16 + e]; }
+          else {
+            qv = ok ? p.q[(size_t)(b * T + i) * p.row_stride + hb + dd] : 0.f;
+            dov = ok ? p.dout[(size_t)(b * T + i) * p.out_row_stride + ohb + dd] : 0.f;
+          }
           // A operand must carry k = i on registers/half with the OUTPUT row (key) on lanes:
           // sd/pd have lane <-> key, register <-> query, i.e. A^T; the MFMA wants A[row=key][k=query].
           // v_mfma A operand: lane l supplies A[row = l&31][k = l>>5]  -> row = key (lane) OK, k = query half.
