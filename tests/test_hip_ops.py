@@ -301,6 +301,59 @@ def test_conv_split_k_with_finishing_launch(cfg, tile, splitk):
     assert L.lib().mmvqa_igemm(C.byref(d), L.KIND_FWD, 0, tile, L.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [(2, 14, 14, 128, 192, 3, 1, 1), (3, 9, 9, 64, 80, 1, 1, 0), (2, 12, 12, 40, 72, 3, 2, 1)])
+def test_conv_every_tile_variant(cfg, tile):
+    """every tile variant the tuner can pick (128x128, 128x64, 64x64 with 64-deep K-tiles, 64x128, the 8-wave form, 64x64
+    with 32-deep K-tiles) on the uniform-tap loaders (channel counts that are multiples of the K-tile) and on the general
+    ones (40 -> 72 channels, stride 2): forward with BN+ReLU prologue and statistics, data gradient with mask and backward
+    statistics, weight gradient -- each against torch"""
+    N, H, W, Cin, Cout, K, s, p = cfg
+    torch.manual_seed(11)
+    x_raw = torch.randn(N, Cin, H, W)
+    sc, sh = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.3
+    w = torch.randn(Cout, Cin, K, K) / math.sqrt(Cin * K * K)
+    a = torch.relu(x_raw * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    z_ref = F.conv2d(a, wr, stride=s, padding=p)
+    OH, OW = z_ref.shape[2:]
+    xd, wd = nhwc(x_raw), w_ohwi(w)
+    scd, shd = sc.to(dev()), sh.to(dev())
+    z = torch.zeros(N * OH * OW, Cout, device=dev())
+    stat = torch.zeros(L.STAT_SLOTS, Cout, 2, dtype=torch.float64, device=dev())
+    d, _, _ = conv_desc_fwd(xd, wd, N, H, W, Cin, Cout, K, s, p, z)
+    d.a_pro, d.a_c0, d.a_c1 = L.PRO_AFFINE_RELU, P(scd), P(shd)
+    d.stat1, d.stat_bwd = P(stat), 0
+    run_igemm(d, L.KIND_FWD, tile=tile)
+    assert_close(from_nhwc(z, N, OH, OW, Cout), z_ref, TOL, "z")
+    st = stat.sum(0).cpu()
+    assert_close(st[:, 0], z_ref.sum(dim=(0, 2, 3)).double(), 1e-5, "sum")
+    assert_close(st[:, 1], (z_ref.double() ** 2).sum(dim=(0, 2, 3)), 1e-5, "sumsq")
+    G = torch.randn_like(z_ref)
+    z_ref.backward(G)
+    Gd = nhwc(G)
+    mu, istd = torch.randn(Cin) * 0.1, torch.rand(Cin) + 0.5
+    mud, isd = mu.to(dev()), istd.to(dev())
+    dx = torch.zeros(N * H * W, Cin, device=dev())
+    bst = torch.zeros(L.STAT_SLOTS, Cin, 2, dtype=torch.float64, device=dev())
+    d = conv_desc_dgrad(Gd, wd, N, H, W, Cin, Cout, K, s, p, dx)
+    d.Mk, d.mk_ld, d.mk_s, d.mk_b = P(xd), Cin, P(scd), P(shd)
+    d.stat1, d.stat_bwd, d.Z1, d.z1_ld, d.mean1, d.invstd1 = P(bst), 1, P(xd), Cin, P(mud), P(isd)
+    run_igemm(d, L.KIND_DGRAD, tile=tile)
+    mask = (x_raw * sc[None, :, None, None] + sh[None, :, None, None] > 0).float()
+    g_ref = a.grad * mask
+    assert_close(from_nhwc(dx, N, H, W, Cin), g_ref, TOL, "dgrad")
+    xhat = (x_raw - mu[None, :, None, None]) * istd[None, :, None, None]
+    bs = bst.sum(0).cpu()
+    assert_close(bs[:, 0], g_ref.sum(dim=(0, 2, 3)).double(), 1e-4, "sum g")
+    assert_close(bs[:, 1], (g_ref * xhat).sum(dim=(0, 2, 3)).double(), 1e-4, "sum g xhat")
+    dw = torch.zeros(Cout, K * K * Cin, device=dev())
+    d = conv_desc_wgrad(Gd, xd, N, H, W, Cin, Cout, K, s, p, dw)
+    d.b_pro, d.b_c0, d.b_c1 = L.PRO_AFFINE_RELU, P(scd), P(shd)
+    run_igemm(d, L.KIND_WGRAD, tile=tile)
+    assert_close(dw.view(Cout, K, K, Cin).permute(0, 3, 1, 2), wr.grad, TOL, "wgrad")
+
+
 def test_stem_conv():
     torch.manual_seed(3)
     N, H, W, Cout = 2, 20, 22, 16
