@@ -168,7 +168,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    # knobs of the gradient exchange for the first real multi-GPU sweeps (defaults = what the driver's runs use)
+    ap.add_argument("--bucket-mb", type=float, default=64.0, help="size of the all-reduce buckets cut from the flat gradient buffer")
+    ap.add_argument("--nccl-algo", type=str, default=None, help="NCCL_ALGO for RCCL (e.g. Ring, Tree)")
+    ap.add_argument("--nccl-proto", type=str, default=None, help="NCCL_PROTO (e.g. Simple, LL, LL128)")
+    ap.add_argument("--nccl-min-nchannels", type=int, default=None, help="NCCL_MIN_NCHANNELS: more channels use more xGMI links at once")
     a = ap.parse_args()
+    for k, v in (("NCCL_ALGO", a.nccl_algo), ("NCCL_PROTO", a.nccl_proto), ("NCCL_MIN_NCHANNELS", a.nccl_min_nchannels)):
+        if v is not None:
+            os.environ[k] = str(v)         # read by RCCL when the communicator is created (init_process_group below)
     global CONFIG, B_PER_GPU, T
     CONFIG = a.config
     if CONFIG == 4:
@@ -201,7 +209,7 @@ def main():
 
     import mmvqa_amd
     from mmvqa_amd import synth
-    from mmvqa_amd.ddp import GradReducer
+    from mmvqa_amd.ddp import GradReducer, comm_info, sync_replicas
 
     torch.manual_seed(1234)            # identical initial weights on every rank
     torch.set_num_threads(min(host_cores(), 16))
@@ -210,10 +218,12 @@ def main():
     model.to(dev).train()
     log(f"model on {dev}: {model.flat_params.numel() / 1e6:.1f} M parameters")
     model.set_seed(1234 + rank)
+    replica_checksum = sync_replicas(model)    # broadcast from rank 0 + checksum equal on every rank (raises otherwise)
     opt = mmvqa_amd.FusedAdam(model, lr=2e-5)
-    red = GradReducer(model.flat_grads)
+    red = GradReducer(model.flat_grads, bucket_mb=a.bucket_mb)
     if world > 1:
-        model.set_grad_ready_hook(red.start)   # all-reduce of finished gradient ranges overlaps the backbone backward
+        # all-reduce of finished gradient ranges overlaps the backbone backward; `ready` orders RCCL's stream explicitly
+        model.set_grad_ready_hook(red.start, with_event=True)
     if CONFIG == 4:
         from mmvqa_amd import train as TR
         va = synth.roco_batch(B_PER_GPU // 2, T, HW, VOCAB, seed=1234 + rank, device=dev)
@@ -336,7 +346,9 @@ def main():
                ms_per_step=ms, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload=wl + "; dropout on, train-mode BN; random-init weights",
                            global_batch=B_PER_GPU * world, seq_len=T, parallelism=f"dp{world}",
-                           samples_per_s_per_gpu=value / world, final_loss=float(last.detach() if hasattr(last, "detach") else last)))
+                           samples_per_s_per_gpu=value / world, final_loss=float(last.detach() if hasattr(last, "detach") else last),
+                           comm=dict(comm_info(red), replica_checksum=replica_checksum,
+                                     rehearsal_on_one_gpu=rehearse)))
     if roof is not None:
         out["roofline"] = roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline and CONFIG == 2:

@@ -21,6 +21,7 @@ def world():
 class GradReducer:
     def __init__(self, flat_grads: torch.Tensor, bucket_mb: float = 64.0):
         self.flat = flat_grads
+        self.bucket_mb = float(bucket_mb)
         n = flat_grads.numel()
         per = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets = []
@@ -32,11 +33,17 @@ class GradReducer:
         self.pending = []
         self.launched = 0
 
-    def start(self, lo=0, hi=None):
+    def start(self, lo=0, hi=None, ready=None):
         """launch async all-reduce (SUM) of every bucket inside [lo, hi).  This is the gradient-ready hook of
         Model.set_grad_ready_hook: called from inside backward, the collective is ordered behind the kernels
-        that produced the range (the communication stream waits for the current stream at call time) and runs
-        beside the rest of the backward pass."""
+        that produced the range and runs beside the rest of the backward pass.
+        `ready`: the event the engine's stream recorded AFTER it joined the side stream that carries the weight
+        gradients of the range (Model.set_grad_ready_hook(..., with_event=True)).  The current stream waits on it
+        before the collective is enqueued -- RCCL's stream then waits for the current stream, so the order
+        side stream -> engine stream -> `ready` -> RCCL stream is explicit rather than implied by which stream
+        happens to be current when the callback fires (gloo synchronises on the host and hides a missing edge)."""
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready)
         if world() == 1:
             return
         hi = self.flat.numel() if hi is None else hi
@@ -57,6 +64,47 @@ class GradReducer:
 
     def allreduce(self):
         self.finish()
+
+
+def sync_replicas(model, src=0):
+    """Make every rank's replica the one of rank `src` and prove it: broadcast the flat parameter buffer, the BatchNorm
+    running statistics and the batch counters, then compare a checksum of all three across ranks (bit-equal or raise).
+    Seeding alone (torch.manual_seed before Model(args)) gives identical replicas only while every rank builds the model
+    with the same library versions and init order; the broadcast does not depend on that.  Returns the checksum."""
+    flat_p, flat_b, flat_n = model._flat[0], model._flat[1], model._flat[2]
+    w = world()
+    if w > 1:
+        for t in (flat_p, flat_b, flat_n):
+            if t.numel():
+                dist.broadcast(t, src=src)
+    cs = torch.stack([flat_p.double().sum(), flat_p.double().abs().sum(), flat_b.double().sum(),
+                      flat_n.double().sum() if flat_n.numel() else flat_p.new_zeros((), dtype=torch.float64)])
+    if w > 1:
+        got = [torch.empty_like(cs) for _ in range(w)]
+        dist.all_gather(got, cs)
+        for r, g in enumerate(got):
+            if not torch.equal(g, got[0]):
+                raise RuntimeError(f"replica of rank {r} differs from rank 0 after the broadcast: {g.tolist()} vs {got[0].tolist()}")
+    return [float(v) for v in cs.tolist()]
+
+
+def comm_info(reducer=None):
+    """what the communicator saw, for the bench line / logs: backend, world size, RCCL version, bucket plan"""
+    info = dict(backend=None, world_size=world(), rccl_version=None)
+    if dist.is_available() and dist.is_initialized():
+        info["backend"] = dist.get_backend()
+        if info["backend"] == "nccl":
+            try:
+                info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as ex:     # the version query is informative only
+                info["rccl_version"] = f"unavailable ({type(ex).__name__})"
+    if reducer is not None:
+        info["buckets"] = len(reducer.buckets)
+        info["bucket_mb"] = reducer.bucket_mb
+        info["gradient_mb"] = reducer.flat.numel() * 4 / (1 << 20)
+    import os
+    info["nccl_env"] = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))}
+    return info
 
 
 class _AllGatherFeat(torch.autograd.Function):

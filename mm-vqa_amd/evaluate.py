@@ -8,12 +8,16 @@ BLEU-1, as vqamed2019/utils.py:690-843 computes them (callers: vqamed2019/train.
   calculate_bleu_score  utils.py:328-330 (mean BLEU-1 of idx2ans[pred] against idx2ans[target])
   category_metrics      utils.py:740-765 / 813-841: total + binary / plane / organ / modality / abnormality, rounded to 4
   validate, test        utils.py:690-767, 769-843: eval-mode forward, mean of the per-batch losses, softmax(1).argmax(1)
+  write_test_files      eval.py:171-178: <model>_preds.csv (the test table + preds / decode_preds / decode_ans) and
+                        <model>_res.txt (image stem | decoded prediction), byte-compatible with what pandas writes there
 
 The forward pass is the HIP engine (mmvqa_amd.Model); the metrics are host bookkeeping on the predicted class ids.
 """
 from __future__ import annotations
 
+import csv
 import math
+import os
 import warnings
 from collections import Counter
 
@@ -91,3 +95,28 @@ def validate(loader, model, criterion, categories, idx2ans, category=None):
 def test(loader, model, criterion, categories, idx2ans, category=None):
     """utils.py:769-843 -> (test_loss, PREDS, acc, bleu)"""
     return _run(loader, model, criterion, categories, idx2ans, category, "")
+
+
+def write_test_files(rows, columns, predictions, idx2ans, out_dir, model_name):
+    """The two files of the reference's test-set run (vqamed2019/eval.py:171-178).
+    rows: the test split as a list of records in loader order, `columns` their field names (img_id, question, answer =
+    class id, category, mode as load_data() leaves them, utils.py:51-79).  Files (same names, columns and separators):
+      <out_dir>/<model_name>_preds.csv  header + one line per sample: the table's own columns, then preds (class id),
+                                        decode_preds, decode_ans; comma separated, minimal quoting, '\n' line ends
+      <out_dir>/<model_name>_res.txt    no header: <image file stem>|<decoded prediction>
+    Returns the two paths."""
+    os.makedirs(out_dir, exist_ok=True)
+    ia, ii = columns.index("answer"), columns.index("img_id")
+    p_csv = os.path.join(out_dir, f"{model_name}_preds.csv")
+    p_res = os.path.join(out_dir, f"{model_name}_res.txt")
+    with open(p_csv, "w", newline="") as f:
+        w = csv.writer(f, lineterminator="\n")
+        w.writerow(list(columns) + ["preds", "decode_preds", "decode_ans"])
+        for rec, p in zip(rows, predictions):
+            w.writerow(list(rec) + [int(p), idx2ans[int(p)], idx2ans[int(rec[ia])]])
+    with open(p_res, "w", newline="") as f:
+        w = csv.writer(f, delimiter="|", lineterminator="\n")
+        for rec, p in zip(rows, predictions):
+            stem = str(rec[ii]).split("/")[-1].split(".")[0]
+            w.writerow([stem, idx2ans[int(p)]])
+    return p_csv, p_res

@@ -361,10 +361,13 @@ class Model(nn.Module):
         return out
 
     # ------------------------------------------------------------------ data-parallel overlap
-    def set_grad_ready_hook(self, fn):
+    def set_grad_ready_hook(self, fn, with_event=False):
         """fn(lo, hi) is called during backward as soon as flat_grads[lo:hi] is final (ordered on the current
         stream), in an order that partitions the whole buffer; pass None to remove.  Used by ddp.GradReducer to
-        start the RCCL all-reduce of finished ranges while the backbone backward is still running."""
+        start the RCCL all-reduce of finished ranges while the backbone backward is still running.
+        with_event=True: fn(lo, hi, ready) also receives a torch.cuda.Event recorded on the engine's stream at the
+        announcement, i.e. after that stream has been ordered behind the side stream's weight gradients of the range
+        (csrc/engine.cpp notify()): any other stream that waits on it may read the range."""
         self._cb_error = None
         if fn is None:
             self._cb = None
@@ -373,7 +376,12 @@ class Model(nn.Module):
 
         def tramp(_user, lo, hi):
             try:
-                fn(int(lo), int(hi))
+                if with_event:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())   # the stream backward was given: already behind the join
+                    fn(int(lo), int(hi), ev)
+                else:
+                    fn(int(lo), int(hi))
             except BaseException as ex:   # exceptions cannot cross the C frame
                 self._cb_error = ex
 

@@ -37,3 +37,20 @@ def vqa_batch(B, T=32, hw=224, vocab=30522, n_classes=1552, seed=1234, device="c
     g = torch.Generator().manual_seed(seed + 77)
     tgt = torch.randint(0, n_classes, (B,), generator=g)
     return tuple(t.to(device) for t in (img, ids, seg, mask, tgt))
+
+
+VQA_CATEGORIES = ("modality", "plane", "organ", "abnormality", "binary")   # the five question types of VQA-Med-2019
+
+
+def vqa_test_table(n, n_classes, seed=1234, data_dir="../ImageClef-2019-VQA-Med"):
+    """A synthetic stand-in for the test split's table as vqamed2019/utils.py:51-79 (load_data) + eval.py:84-97 leave
+    it: columns (img_id, question, answer, category, mode) with img_id a path under <data_dir>/Test/images, answer the
+    class id.  Returns (columns, rows, idx2ans)."""
+    g = torch.Generator().manual_seed(seed + 4242)
+    ans = torch.randint(0, n_classes, (n,), generator=g).tolist()
+    cat = torch.randint(0, len(VQA_CATEGORIES), (n,), generator=g).tolist()
+    cols = ["img_id", "question", "answer", "category", "mode"]
+    rows = [(f"{data_dir}/Test/images/synpic{10000 + i}.jpg", f"what is shown in image {i}?", ans[i], VQA_CATEGORIES[cat[i]], "test")
+            for i in range(n)]
+    idx2ans = {i: f"answer {i}" if i % 3 else f"finding, type {i}" for i in range(n_classes)}
+    return cols, rows, idx2ans

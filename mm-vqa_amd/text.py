@@ -180,65 +180,76 @@ def get_keywords(med_vocab: dict):
     return list(set(keywords))
 
 
-def mask_word(sentence, tokenizer, keywords, mlm_prob, rng=_random):
-    """roco_utils.py:135-160.  One `rng.random()` draw per word piece of every keyword word, in order."""
+def _masked_pieces(sentence, tokenizer, keywords, mlm_prob, rng):
+    """Word pieces of a caption with keyword pieces masked: yields (piece or '[MASK]', label id) pairs.
+    Contract with pretrain/roco_utils.py:135-160 (what the fixtures pin): words are the whitespace fields of the
+    caption; only words that are themselves in the keyword set take part; EVERY piece of such a word consumes exactly
+    one rng.random() draw, in reading order, and is masked when the draw is below mlm_prob; the label of a masked piece
+    is the id of the first piece of that piece's own string re-tokenised (so '##ing' is labelled by the id of '#')."""
     kw = keywords if isinstance(keywords, (set, frozenset)) else set(keywords)
-    tokens = sentence.split()
-    output_label, new_tokens = [], []
-    for char in tokens:
-        t = tokenizer.tokenize(char)
-        if char in kw:
-            for j in range(len(t)):
-                prob = rng.random()
-                if prob < mlm_prob:
-                    output_label.append(tokenizer.encode(t[j])[1])   # (sic) id of the first piece of the STRING t[j]
-                    t[j] = "[MASK]"
-                else:
-                    output_label.append(0)
-            new_tokens.extend(t)
-        else:
-            new_tokens.extend(t)
-            output_label.extend([0] * len(t))
-    assert len(new_tokens) == len(output_label), "Token len must be equal to label len"
-    return new_tokens, output_label
+    for word in sentence.split():
+        pieces = tokenizer.tokenize(word)
+        if word not in kw:
+            for pc in pieces:
+                yield pc, 0
+            continue
+        hits = [rng.random() < mlm_prob for _ in pieces]
+        for pc, hit in zip(pieces, hits):
+            if hit:
+                yield "[MASK]", tokenizer.encode(pc)[1]
+            else:
+                yield pc, 0
+
+
+def mask_word(sentence, tokenizer, keywords, mlm_prob, rng=_random):
+    """roco_utils.py:135-160 -> (word pieces with masks applied, label id per piece)"""
+    pairs = list(_masked_pieces(sentence, tokenizer, keywords, mlm_prob, rng))
+    return [pc for pc, _ in pairs], [lab for _, lab in pairs]
+
+
+def _fill_row(ids, seg, mask, text_ids, n_vis, cls_id, sep_id):
+    """One row of the model's token layout, written in place into zeroed length-T rows:
+        position   0      1 .. n_vis     n_vis+1   n_vis+2 .. n_vis+1+n   n_vis+2+n   rest
+        ids        [CLS]  0 (visual)     [SEP]     text piece ids         [SEP]       0
+        seg        0      0              0         1                      1           0
+        mask       1      1              1         1                      1           0
+    (pretrain/roco_utils.py:176-186 and vqamed2019/utils.py:160-168 build the same rows by list concatenation.)
+    Returns the position of the first text piece."""
+    n, t0 = len(text_ids), n_vis + 2
+    ids[0] = cls_id
+    ids[n_vis + 1] = sep_id
+    if n:
+        ids[t0:t0 + n] = torch.as_tensor(text_ids, dtype=torch.long)
+    ids[t0 + n] = sep_id
+    seg[t0:t0 + n + 1] = 1
+    mask[:t0 + n + 1] = 1
+    return t0
 
 
 def encode_text(caption, tokenizer, keywords, num_vis, max_position_embeddings, mlm_prob, rng=_random):
     """roco_utils.py:162-199 (task 'MLM') -> (tokens, segment_ids, input_mask, labels), int64 tensors of length
-    max_position_embeddings"""
-    total_special = num_vis + 3
-    part1 = [0] * num_vis
-    caption, labels = mask_word(caption, tokenizer, keywords, mlm_prob, rng)
-    part2 = tokenizer.convert_tokens_to_ids(caption)
-    part2 = part2[:max_position_embeddings - total_special]
-    labels = labels[:max_position_embeddings - total_special]
-    tokens = [tokenizer.cls_token_id] + part1 + [tokenizer.sep_token_id] + part2 + [tokenizer.sep_token_id]
-    segment_ids = [0] * (len(part1) + 2) + [1] * (len(part2) + 1)
-    input_mask = [1] * len(tokens)
-    n_pad = max_position_embeddings - len(tokens)
-    tokens.extend([0] * n_pad)
-    segment_ids.extend([0] * n_pad)
-    input_mask.extend([0] * n_pad)
-    labels = [0] * (2 + len(part1)) + labels + [0]
-    labels.extend([0] * n_pad)
-    return (torch.tensor(tokens, dtype=torch.long), torch.tensor(segment_ids, dtype=torch.long),
-            torch.tensor(input_mask, dtype=torch.long), torch.tensor(labels, dtype=torch.long))
+    max_position_embeddings; the caption keeps its first max_position_embeddings - (num_vis + 3) pieces (the RNG is
+    still drawn for the pieces that are cut: masking happens before truncation)"""
+    T = max_position_embeddings
+    pieces, piece_labels = mask_word(caption, tokenizer, keywords, mlm_prob, rng)
+    room = T - (num_vis + 3)
+    text_ids = tokenizer.convert_tokens_to_ids(pieces)[:room]
+    ids, seg, mask, lab = (torch.zeros(T, dtype=torch.long) for _ in range(4))
+    t0 = _fill_row(ids, seg, mask, text_ids, num_vis, tokenizer.cls_token_id, tokenizer.sep_token_id)
+    if text_ids:
+        lab[t0:t0 + len(text_ids)] = torch.as_tensor(piece_labels[:room], dtype=torch.long)
+    return ids, seg, mask, lab
 
 
 # --------------------------------------------------------------------------- VQA-Med (vqamed2019/utils.py)
 def encode_text_vqa(question, tokenizer, max_position_embeddings):
-    """utils.py:156-170: always 5 visual slots, question truncated to max_position_embeddings - 8 pieces"""
-    part1 = [0] * 5
-    part2 = tokenizer.encode(question)[1:-1]
-    keep = part2[:max_position_embeddings - 8]
-    tokens = [tokenizer.cls_token_id] + part1 + [tokenizer.sep_token_id] + keep + [tokenizer.sep_token_id]
-    segment_ids = [0] * (len(part1) + 2) + [1] * (len(keep) + 1)
-    input_mask = [1] * len(tokens)
-    n_pad = max_position_embeddings - len(tokens)
-    tokens.extend([0] * n_pad)
-    segment_ids.extend([0] * n_pad)
-    input_mask.extend([0] * n_pad)
-    return tokens, segment_ids, input_mask
+    """utils.py:156-170 -> (tokens, segment_ids, input_mask) as lists: always 5 visual slots, the question keeps its
+    first max_position_embeddings - 8 pieces"""
+    T = max_position_embeddings
+    text_ids = tokenizer.convert_tokens_to_ids(tokenizer.tokenize(question))[:T - 8]
+    ids, seg, mask = (torch.zeros(T, dtype=torch.long) for _ in range(3))
+    _fill_row(ids, seg, mask, text_ids, 5, tokenizer.cls_token_id, tokenizer.sep_token_id)
+    return ids.tolist(), seg.tolist(), mask.tolist()
 
 
 # --------------------------------------------------------------------------- batches for the hot path

@@ -4,6 +4,7 @@ which never ship to the GPU box (SURVEY.md 8(b) "Callers the build must supply")
   mlm      pretrain/roco_train.py:155-197 + pretrain/roco_utils.py:207-372 (train_one_epoch / validate)
   supcon   pretrain/roco_supcon_train.py:137,168-202 + models/SupConLoss/supcon_utils.py:253-379
   vqa      vqamed2019/train.py:125-296 + vqamed2019/utils.py:625-767
+  eval     vqamed2019/eval.py:99-180 + vqamed2019/utils.py:769-843 (test-set run: metrics, <model>_preds.csv, <model>_res.txt)
 
 Kept from the reference: option names and defaults, Adam(lr) + ReduceLROnPlateau(patience, factor) on the
 validation loss, zero_grad -> forward -> loss -> backward -> step order, loss / accuracy definitions,
@@ -15,6 +16,7 @@ layout stand in: mmvqa_amd.synth), wandb, BLEU.  One process per GPU under torch
     python -m mmvqa_amd.train mlm    --run_name r --mlm_prob 0.15 --epochs 2 --steps_per_epoch 20
     python -m mmvqa_amd.train supcon --run_name r --mlm_prob 0.15 --batch_size 32
     python -m mmvqa_amd.train vqa    --run_name r --loss ASLSingleLabel --batch_size 64
+    python -m mmvqa_amd.train eval   --model_dir save/MLM/r.pt --num_classes 1552 --batch_size 16
 """
 from __future__ import annotations
 
@@ -26,8 +28,8 @@ import torch
 import torch.distributed as dist
 from torch.optim import lr_scheduler
 
-from . import FusedAdam, Model, asl_loss, checkpoint, mlm_loss, split_feat, supcon_loss, synth
-from .ddp import GradReducer, global_supcon_views
+from . import FusedAdam, Model, asl_loss, checkpoint, evaluate, mlm_loss, split_feat, supcon_loss, synth
+from .ddp import GradReducer, comm_info, global_supcon_views, sync_replicas
 
 
 def common_args(p):
@@ -62,6 +64,7 @@ def common_args(p):
     p.add_argument("--resnet_layers", type=int, nargs=4, default=[3, 8, 36, 3])
     p.add_argument("--resnet_width", type=int, default=64)
     p.add_argument("--emb_vocab", type=int, default=30522)
+    p.add_argument("--bucket_mb", type=float, default=64.0, help="all-reduce bucket size (data parallel)")
 
 
 class Ctx:
@@ -110,11 +113,14 @@ def build(args, ctx, n_classes=None):
         checkpoint.load_model(model, args.resume_dir)
     model.to(ctx.dev)
     model.set_seed(args.seed + ctx.rank)
+    cs = sync_replicas(model)              # rank 0's replica everywhere, checksum compared across ranks
     opt = FusedAdam(model, lr=args.lr)
     sched = lr_scheduler.ReduceLROnPlateau(_SchedShim(opt), patience=args.patience, factor=args.factor)
-    red = GradReducer(model.flat_grads)
+    red = GradReducer(model.flat_grads, bucket_mb=getattr(args, "bucket_mb", 64.0))
     if ctx.world > 1:
-        model.set_grad_ready_hook(red.start)
+        model.set_grad_ready_hook(red.start, with_event=True)
+        if ctx.rank == 0:
+            print(f"data parallel: {comm_info(red)} replica checksum {cs}", flush=True)
     return model, opt, sched, red
 
 
@@ -128,11 +134,15 @@ class _SchedShim(torch.optim.Optimizer):
         self.state = {}
 
 
-def save_recorder(args, epoch, model, opt, sched):
-    """the 5-epoch "recorder" dict of roco_train.py:164-171 / roco_supcon_train.py:177-184"""
+def save_recorder(args, epoch, model, opt, sched, mode, best=None):
+    """the 5-epoch "recorder" dict of roco_train.py:164-171 / roco_supcon_train.py:177-184 (keys epoch, optimizer,
+    scheduler, scaler, model), plus two keys the reference's dict lacks: which loop wrote it and the best-so-far
+    trackers -- without them a resumed run re-saves its "best" checkpoint in the first epoch whatever the loss, and a
+    recorder of another loop in the same save_dir is loaded blindly."""
     os.makedirs(args.save_dir, exist_ok=True)
     torch.save({"epoch": epoch, "optimizer": opt.state_dict(), "scheduler": sched.state_dict(), "scaler": {},
-                "model": model.state_dict()}, os.path.join(args.save_dir, "recorder_2.pt"))
+                "model": model.state_dict(), "mode": mode, "best": dict(best or {})},
+               os.path.join(args.save_dir, "recorder_2.pt"))
 
 
 def save_model(args, model, suffix=""):
@@ -143,15 +153,18 @@ def save_model(args, model, suffix=""):
     torch.save(model.state_dict(), os.path.join(d, args.run_name + suffix + ".pt"))
 
 
-def maybe_resume(args, model, opt, sched):
+def maybe_resume(args, model, opt, sched, mode):
+    """-> (first epoch to run, best-so-far trackers of the interrupted run)"""
     path = os.path.join(args.save_dir, "recorder_2.pt")
     if not (args.resume and os.path.exists(path)):
-        return 0
+        return 0, {}
     rec = torch.load(path, map_location="cpu", weights_only=False)
+    if rec.get("mode", mode) != mode:
+        raise RuntimeError(f"{path} was written by the '{rec['mode']}' loop, this is '{mode}': refusing to resume from it")
     model.load_state_dict(rec["model"])
     opt.load_state_dict(rec["optimizer"])
     sched.load_state_dict(rec["scheduler"])
-    return rec["epoch"] + 1
+    return rec["epoch"] + 1, dict(rec.get("best") or {})
 
 
 # ----------------------------------------------------------------------------------------- one training step each
@@ -214,7 +227,8 @@ def run_mlm(args):
     args.dataset, args.task = "roco", "MLM"
     model, opt, sched, red = build(args, ctx)
     T, B, V = args.max_position_embeddings, args.batch_size, args.vocab_size
-    best, start = float("inf"), maybe_resume(args, model, opt, sched)
+    start, kept = maybe_resume(args, model, opt, sched, "mlm")
+    best = kept.get("best", float("inf"))
     for epoch in range(start, args.epochs):
         model.train()
         tl, nm, nc = 0.0, 0.0, 0.0
@@ -228,7 +242,7 @@ def run_mlm(args):
         vl, va = validate_mlm(args, ctx, model, epoch)
         sched.step(vl)
         if (epoch + 1) % 5 == 0 and ctx.rank == 0:
-            save_recorder(args, epoch, model, opt, sched)
+            save_recorder(args, epoch, model, opt, sched, "mlm", {"best": min(best, vl)})
         tl = ctx.mean(tl / args.steps_per_epoch)
         if ctx.rank == 0:
             print(f"Epoch {epoch + 1}/{args.epochs} Learning rate: {opt.param_groups[0]['lr']:.7f}, Train loss: {tl:.4f}, "
@@ -264,7 +278,8 @@ def run_supcon(args):
     n = args.batch_size // 2                      # roco_supcon_train.py:137: the loader yields bs//2 pairs
     if n < 1:
         raise ValueError("--batch_size must be >= 2 (two views per sample)")
-    best, start = float("inf"), maybe_resume(args, model, opt, sched)
+    start, kept = maybe_resume(args, model, opt, sched, "supcon")
+    best = kept.get("best", float("inf"))
     for epoch in range(start, args.epochs):
         model.train()
         tl = 0.0
@@ -278,7 +293,7 @@ def run_supcon(args):
         vl, va = validate_mlm(args, ctx, model, epoch)
         sched.step(vl)
         if (epoch + 1) % 5 == 0 and ctx.rank == 0:       # roco_supcon_train.py:177-184
-            save_recorder(args, epoch, model, opt, sched)
+            save_recorder(args, epoch, model, opt, sched, "supcon", {"best": min(best, vl)})
         if ctx.rank == 0:
             print(f"Epoch {epoch + 1}/{args.epochs} Learning rate: {opt.param_groups[0]['lr']:.7f}, "
                   f"Train loss: {tl / args.steps_per_epoch:.4f}, Val loss: {vl:.4f}, Val acc: {va:.4f}", flush=True)
@@ -296,9 +311,10 @@ def run_vqa(args):
     model, opt, sched, red = build(args, ctx, n_classes=C)
     T, B = args.max_position_embeddings, args.batch_size
     crit = (lambda lg, t: asl_loss(lg, t)) if args.loss == "ASLSingleLabel" else (lambda lg, t: mlm_loss(lg, t)[0])
-    best_loss, best_acc1, best_acc2, counter = float("inf"), 0.0, 0.0, 0
     # (vqamed2019/train.py itself has no recorder / --resume; kept here like the two pre-training loops)
-    start = maybe_resume(args, model, opt, sched)
+    start, kept = maybe_resume(args, model, opt, sched, "vqa")
+    best_loss, best_acc1 = kept.get("best_loss", float("inf")), kept.get("best_acc1", 0.0)
+    best_acc2, counter = kept.get("best_acc2", 0.0), kept.get("counter", 0)
     for epoch in range(start, args.epochs):
         model.train()
         tl = 0.0
@@ -321,8 +337,6 @@ def run_vqa(args):
         if ctx.rank == 0:
             print(f"Epoch {epoch + 1}/{args.epochs} lr {opt.param_groups[0]['lr']:.7f} train_loss {tl / args.steps_per_epoch:.4f} "
                   f"val_loss {vl:.4f} val_total_acc {acc:.2f}", flush=True)
-        if (epoch + 1) % 5 == 0 and ctx.rank == 0:
-            save_recorder(args, epoch, model, opt, sched)
         if ctx.rank == 0:
             if vl < best_loss:                   # train.py:264-268 "save by val loss"
                 save_model(args, model, "_loss")
@@ -330,20 +344,64 @@ def run_vqa(args):
                 save_model(args, model)
         best_loss = min(best_loss, vl)
         best_acc1 = max(best_acc1, acc)
+        expired = False
         if best_acc1 > best_acc2:                # train.py:288-296 early stop
             counter, best_acc2 = 0, best_acc1
         else:
             counter += 1
-            if counter > args.counter:
-                if ctx.rank == 0:
-                    print("Counter expired, finishing.")
-                break
+            expired = counter > args.counter
+        if (epoch + 1) % 5 == 0 and ctx.rank == 0:
+            save_recorder(args, epoch, model, opt, sched, "vqa",
+                          dict(best_loss=best_loss, best_acc1=best_acc1, best_acc2=best_acc2, counter=counter))
+        if expired:
+            if ctx.rank == 0:
+                print("Counter expired, finishing.")
+            break
     return best_loss
+
+
+# ----------------------------------------------------------------------------------------- VQA-Med-2019 test-set run
+def run_eval(args):
+    """vqamed2019/eval.py:99-180: Model(args) -> classifier[2] = Linear(hidden, num_classes) -> load_state_dict(model_dir)
+    -> test() over the test split (batch_size, shuffle False) -> print acc / bleu -> <model_name>_preds.csv and
+    <model_name>_res.txt in save_dir.  The test split is synthetic (mmvqa_amd.synth.vqa_test_table + vqa_batch: the
+    dataset and its tokenizer are not in the image); everything after the loader is the reference's sequence."""
+    ctx = Ctx(args)
+    args.dataset, args.task = "VQA-Med", "MLM"
+    C = args.num_classes
+    torch.manual_seed(args.seed)
+    model = Model(args)
+    model.classifier[2] = torch.nn.Linear(args.hidden_size, C)                     # eval.py:109
+    if args.model_dir:
+        print("Loading model at ", args.model_dir)
+        model.load_state_dict(checkpoint.read_state_dict(args.model_dir))        # eval.py:112
+    model.to(ctx.dev)
+    crit = (lambda lg, t: asl_loss(lg, t)) if args.loss == "ASLSingleLabel" else (lambda lg, t: mlm_loss(lg, t)[0])
+    cols, rows, idx2ans = synth.vqa_test_table(args.test_samples, C, seed=args.seed)
+    B, T = args.batch_size, args.max_position_embeddings
+
+    def loader():                                                                # DataLoader(testdataset, batch_size, shuffle=False)
+        for lo in range(0, len(rows), B):
+            n = min(B, len(rows) - lo)
+            img, ids, seg, mask, _ = synth.vqa_batch(n, T, args.image_size, args.emb_vocab, C, seed=args.seed + lo, device=ctx.dev)
+            tgt = torch.tensor([r[2] for r in rows[lo:lo + n]], dtype=torch.long, device=ctx.dev)
+            yield img, ids, seg, mask, tgt
+
+    cats = [r[3] for r in rows]
+    test_loss, predictions, acc, bleu = evaluate.test(loader(), model, crit, cats, idx2ans, category=args.category)
+    model_name = (args.model_dir or args.run_name).split("/")[-1]               # eval.py:68
+    if ctx.rank == 0:
+        paths = evaluate.write_test_files(rows, cols, predictions, idx2ans, args.save_dir, model_name)   # eval.py:171-178
+        print("test_loss", float(test_loss))
+        print("acc", acc)
+        print("bleu", bleu)
+        print("wrote", *paths)
+    return test_loss, acc, bleu
 
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    mode = argv.pop(0) if argv and argv[0] in ("mlm", "supcon", "vqa") else "mlm"
+    mode = argv.pop(0) if argv and argv[0] in ("mlm", "supcon", "vqa", "eval") else "mlm"
     p = argparse.ArgumentParser(description=f"mmvqa_amd training ({mode})")
     common_args(p)
     if mode in ("mlm", "supcon"):
@@ -364,8 +422,10 @@ def main(argv=None):
         p.add_argument("--model_dir", type=str, default=None, help="ROCO-pretrained Model state_dict")
         p.add_argument("--resume_training", action="store_true", default=False)
         p.add_argument("--resume_dir", type=str, default=None, help="fine-tuned Model state_dict to continue from")
+        p.add_argument("--category", type=str, default=None, help="eval: one question category only (eval.py:29)")
+        p.add_argument("--test_samples", type=int, default=64, help="eval: size of the synthetic test split")
     args = p.parse_args(argv)
-    out = {"mlm": run_mlm, "supcon": run_supcon, "vqa": run_vqa}[mode](args)
+    out = {"mlm": run_mlm, "supcon": run_supcon, "vqa": run_vqa, "eval": run_eval}[mode](args)
     if dist.is_initialized():
         dist.destroy_process_group()
     return out

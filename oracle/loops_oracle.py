@@ -8,8 +8,10 @@ lacks -- wandb, nltk, pytorch_lightning, sentence_transformers, googletrans, ber
 name-only stubs), runs THEIR train_one_epoch functions on the reference Model for two batches and records per-step
 losses, accuracy and the parameters after the two Adam steps (tests/golden/loop_*.npz);
 tests/test_oracle_golden.py::test_loops_match_reference_loops replays them through this file.
-The evaluation half (validate / test) depends on nltk's sentence_bleu, which is absent: BLEU-1 is restated from the
-published algorithm and marked "parity unpinned" below; the bookkeeping around it follows the source text.
+The evaluation half (validate / test, vqamed2019/utils.py:690-843) is pinned the same way (loop_vqa_eval.npz: the
+reference's own functions on a loader with mixed categories, one of them empty); only nltk's sentence_bleu inside it
+is absent from the image: BLEU-1 is restated from the published algorithm, marked "parity unpinned" below and anchored
+by hand-computed known answers; the fixture script hands this restatement to the reference's calculate_bleu_score.
 
 A "loader" here is any iterable of batches with the reference's tuple layout (already on the CPU).
 """
@@ -102,6 +104,18 @@ def vqa_train_one_epoch(loader, model, optimizer, criterion, clip=False):
     return np.mean(train_loss), (P == T).mean() * 100., train_loss, PREDS
 
 
+def perturb_bn_buffers(model, seed):
+    """test helper: eval-mode BatchNorm reads its running buffers; a freshly built model has them at (0, 1), where a
+    mistake in their use is invisible.  Moves every BatchNorm2d buffer to seeded values (the fixture script and the
+    replaying tests call this on the same seeded oracle model)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
 # --------------------------------------------------------------------------- evaluation (vqamed2019/utils.py:690-843)
 def sentence_bleu_unigram(references, hypothesis):
     """nltk.translate.bleu_score.sentence_bleu(references, hypothesis, weights=[1]) -- third-party (nltk, version
@@ -139,9 +153,11 @@ def calculate_bleu_score(preds, targets, idx2ans):
     return np.mean(bleu_per_answer)
 
 
-def vqa_validate(loader, model, criterion, val_category, idx2ans, prefix="val_"):
-    """vqamed2019/utils.py:690-767 (validate, prefix 'val_') and :769-843 (test, prefix ''), args.category unset,
-    args.mixed_precision / args.smoothing False.  val_category = val_df['category'] as a numpy array of strings."""
+def vqa_validate(loader, model, criterion, val_category, idx2ans, prefix="val_", category=None):
+    """vqamed2019/utils.py:690-767 (validate, prefix 'val_') and :769-843 (test, prefix ''),
+    args.mixed_precision / args.smoothing False.  val_category = val_df['category'] as a numpy array of strings;
+    category = args.category (set: one accuracy and one BLEU number, :741-743).
+    PINNED by tests/golden/loop_vqa_eval.npz: the reference's own validate / test on a mixed-category loader."""
     model.eval()
     val_loss, PREDS, TARGETS = [], [], []
     with torch.no_grad():
@@ -155,6 +171,8 @@ def vqa_validate(loader, model, criterion, val_category, idx2ans, prefix="val_")
         val_loss = np.mean(val_loss)
     PREDS = torch.cat(PREDS).cpu().numpy()
     TARGETS = torch.cat(TARGETS).cpu().numpy()
+    if category:
+        return val_loss, PREDS, (PREDS == TARGETS).mean() * 100., calculate_bleu_score(PREDS, TARGETS, idx2ans)
     cat = np.asarray(val_category)
     names = (("total", None), ("binary", "binary"), ("plane", "plane"), ("organ", "organ"), ("modality", "modality"),
              ("abnorm", "abnormality"))
@@ -164,3 +182,17 @@ def vqa_validate(loader, model, criterion, val_category, idx2ans, prefix="val_")
         acc[prefix + short + "_acc"] = np.round((PREDS[sel] == TARGETS[sel]).mean() * 100., 4)
         bleu[prefix + short + "_bleu"] = np.round(calculate_bleu_score(PREDS[sel], TARGETS[sel], idx2ans), 4)
     return val_loss, PREDS, acc, bleu
+
+
+def eval_write_csvs(test_df, predictions, idx2ans, out_dir, model_name):
+    """vqamed2019/eval.py:171-178: the two files the test-set run leaves behind, written with pandas as the
+    reference does.  test_df: the test split's DataFrame (columns img_id, question, answer (class id), category, mode)."""
+    import os
+    test_df = test_df.copy()
+    test_df['preds'] = predictions                                                          # :171
+    test_df['decode_preds'] = test_df['preds'].map(idx2ans)                                 # :172
+    test_df['decode_ans'] = test_df['answer'].map(idx2ans)                                  # :173
+    test_df.to_csv(os.path.join(out_dir, f'{model_name}_preds.csv'), index=False)           # :174
+    result = test_df[['img_id', 'decode_preds']].copy()                                     # :176
+    result['img_id'] = result['img_id'].apply(lambda x: x.split('/')[-1].split('.')[0])     # :177
+    result.to_csv(os.path.join(out_dir, f'{model_name}_res.txt'), index=False, header=False, sep='|')   # :178

@@ -9,9 +9,12 @@
 Run ONCE in the build container:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_loops.py
 
 Packages the image lacks are NAME-ONLY stubs (wandb, nltk, pytorch_lightning, sentence_transformers, googletrans,
-bert_score, torchvision, timm); `sentence_bleu` is a stub returning 0.0 (the VQA loop computes a BLEU figure at the end
-of the epoch which these fixtures do not record).  Model weights are seeded oracle weights copied into the reference
-Model (state_dict names are identical), optimizer = torch.optim.Adam as the scripts build it.  Stored: the batches,
+bert_score, torchvision, timm); `sentence_bleu` is a stub returning 0.0 in the training loops (the VQA loop computes a BLEU
+figure at the end of the epoch which those fixtures do not record) and the build's own unigram BLEU
+(oracle.loops_oracle.sentence_bleu_unigram) in the evaluation fixture `loop_vqa_eval`, which runs the reference's own
+`validate` and `test` (vqamed2019/utils.py:690-843) on a loader with mixed categories -- one category empty -- so that the
+per-category bookkeeping, the NaN of an empty category, the rounding and the key names are pinned.  Model weights are
+seeded oracle weights copied into the reference Model (state_dict names are identical), optimizer = torch.optim.Adam as the scripts build it.  Stored: the batches,
 the per-step losses (recorded by wrapping the criterion objects), the returned (mean loss, accuracy) and samples of
 the parameters AFTER the two optimizer steps.  Data only.
 """
@@ -32,6 +35,7 @@ from transformers import BertTokenizer, BertModel, AutoTokenizer, AutoModel  # n
 import make_golden as MG  # noqa: E402  (stubs torchvision/timm, imports the reference model modules)
 from make_golden_text import stub, register_stubs  # noqa: E402
 from oracle import mmbert_oracle as O  # noqa: E402
+from oracle import loops_oracle as LO  # noqa: E402
 from mmvqa_amd import synth  # noqa: E402
 
 register_stubs()
@@ -164,7 +168,68 @@ def loop_vqa():
     finish("loop_vqa", ref, extra, ["transformer.mains.0.proj.weight", "transformer.mains.1.ff.0.weight"])
 
 
+# answers in pairs (2k, 2k+1) that share words (partial BLEU-1 credit, brevity penalty, clipping) or share none
+EVAL_ANSWERS = ["ct with contrast", "ct", "yes", "no", "mr flair", "mr t2 weighted flair", "left lung", "right lung",
+                "axial", "coronal", "pulmonary embolism", "embolism", "us doppler", "xr plain film", "brain", "heart",
+                "t1", "pe", "sagittal", "angiogram", "the", "an the the", "lung"]
+EVAL_CATEGORIES = ["binary", "plane", "modality", "abnormality", "plane", "modality"]   # no 'organ': nan in the reference
+
+
+def loop_vqa_eval():
+    """vqamed2019/utils.py:690-767 (validate) and :769-843 (test) run as they stand: eval-mode forward (BatchNorm on its
+    running buffers, which are moved off their defaults first), mean of the per-batch losses, softmax(1).argmax(1),
+    total + per-category accuracy / BLEU-1 rounded to 4, and the --category form (one number each)."""
+    import pandas as pd
+    C, B, T, hw, nb = 23, 4, 10, 64, 3
+    kw = dict(transformer_model="realformer", dataset="VQA-Med", hidden_size=768, n_layers=2, heads=12,
+              hidden_dropout_prob=0.0, vocab_size=C, resnet_layers=(1, 1, 1, 1), resnet_width=64, bert_max_pos=32,
+              use_relu=False, cnn_encoder="resnet152")
+    args = O.make_args(**kw)
+    torch.manual_seed(61)
+    orc = O.OracleModel(args)
+    LO.perturb_bn_buffers(orc, seed=62)
+    ref = MG.build_ref_model(args, orc)
+    MG.zero_dropout(ref)
+    batches = [synth.vqa_batch(B, T, hw, vocab=C, n_classes=C, seed=95 + i) for i in range(nb)]
+    # targets: what the model predicts, except four samples that get the paired answer (so that every kind of accuracy
+    # and BLEU value occurs: 100, 50, 75, partial unigram credit)
+    ref.eval()
+    fixed = []
+    with torch.no_grad():
+        for bi, (img, ids, seg, mask, _) in enumerate(batches):
+            pred = ref(img, ids, seg, mask)[0].softmax(1).argmax(1)
+            j = torch.arange(B) + bi * B
+            miss = (j == 1) | (j == 4) | (j == 6) | (j == 11)
+            tgt = torch.where(miss, torch.where(pred == C - 1, pred - 1, pred ^ 1), pred)
+            fixed.append((img, ids, seg, mask, tgt))
+    batches = fixed
+    cats = np.array([EVAL_CATEGORIES[i % len(EVAL_CATEGORIES)] for i in range(B * nb)])
+    val_df = pd.DataFrame({"category": cats})
+    idx2ans = {i: a for i, a in enumerate(EVAL_ANSWERS)}
+    assert len(idx2ans) == C
+    VU.sentence_bleu = lambda refs, hyp, weights=None: LO.sentence_bleu_unigram(refs, hyp)
+    loader = [(img, ids.unsqueeze(1), seg, mask.unsqueeze(1), tgt, ["p"] * B) for img, ids, seg, mask, tgt in batches]
+    a = types.SimpleNamespace(mixed_precision=False, smoothing=False, category=None)
+    extra = dict(seed=61, bn_seed=62, dims=[B, T, hw, C, nb], categories=cats, answers=np.array(EVAL_ANSWERS))
+    for name, fn, crit in (("val", VU.validate, Recorder(ASLSingleLabel())),          # train.py:172-174 / :230
+                           ("test", VU.test, Recorder(torch.nn.CrossEntropyLoss()))):  # eval.py:128,144
+        loss, PREDS, acc, bleu = fn(loader, ref, crit, "cpu", None, a, val_df, idx2ans)
+        extra.update({f"{name}_loss": loss, f"{name}_preds": PREDS, f"{name}_batch_losses": np.array(crit.values),
+                      f"{name}_acc_keys": np.array(list(acc.keys())), f"{name}_acc_vals": np.array(list(acc.values()), dtype=np.float64),
+                      f"{name}_bleu_keys": np.array(list(bleu.keys())), f"{name}_bleu_vals": np.array(list(bleu.values()), dtype=np.float64)})
+        assert not ref.training
+    # --category <name> (utils.py:741-743 / :813-815): plain numbers
+    a.category = "plane"
+    loss, PREDS, acc, bleu = VU.validate(loader, ref, Recorder(ASLSingleLabel()), "cpu", None, a, val_df, idx2ans)
+    extra.update(cat_acc=acc, cat_bleu=bleu)
+    for i, b in enumerate(batches):
+        for n, t in zip(("img", "ids", "seg", "mask", "tgt"), b):
+            extra[f"{n}{i}"] = t
+    MG.save("loop_vqa_eval", **extra)
+
+
 if __name__ == "__main__":
     loop_mlm()
     loop_supcon()
     loop_vqa()
+    loop_vqa_eval()

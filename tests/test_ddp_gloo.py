@@ -16,7 +16,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from mmvqa_amd.ddp import GradReducer, global_supcon_views
+    from mmvqa_amd.ddp import GradReducer, comm_info, global_supcon_views, sync_replicas
     from oracle import mmbert_oracle as O
     try:
         # 1. bucketed all-reduce of a flat gradient buffer (buckets smaller than the buffer, ragged tail)
@@ -51,7 +51,16 @@ def _worker(rank, world, port, q):
         ref.backward()
         gref = torch.cat([ref_in.grad[rank * n:(rank + 1) * n, 0], ref_in.grad[rank * n:(rank + 1) * n, 1]], 0)
         ok3 = abs(float(loss) - float(ref)) < 1e-6 and torch.allclose(local.grad, gref * world, atol=1e-5)
-        q.put((rank, ok1, ok2, ok3))
+        # 4. start-up: replicas that were built differently are made rank 0's, and the checksum agrees afterwards
+        import types
+        torch.manual_seed(500 + rank)
+        fake = types.SimpleNamespace(_flat=[torch.randn(1003), torch.randn(77), torch.full((5,), rank, dtype=torch.long)])
+        cs = sync_replicas(fake)
+        torch.manual_seed(500)
+        ok4 = torch.equal(fake._flat[0], torch.randn(1003)) and torch.equal(fake._flat[1], torch.randn(77)) and int(fake._flat[2].sum()) == 0
+        info = comm_info(red)
+        ok4 = ok4 and info["backend"] == "gloo" and info["world_size"] == world and info["buckets"] == len(red.buckets) and len(cs) == 4
+        q.put((rank, ok1, ok2, ok3 and ok4))
     finally:
         dist.destroy_process_group()
 

@@ -88,7 +88,10 @@ def oracle_loss(kind, out, tgt, B):
     return O.mlm_loss(out, tgt)[0]
 
 
-def run_case(args, B, T, hw, kind, seed=0, stat_tol=1e-4):
+def run_case(args, B, T, hw, kind, seed=0, stat_tol=1e-4, tune=False):
+    """tune=True: the launcher's timed per-shape choices (tile, split-K, K split + finishing launch) are made first --
+    Model.tune() on the case's own inputs, as bench.py and train.py do -- so that the kernels compared with the oracle
+    are the ones the timed steps run."""
     orc, hip = build_pair(args, seed)
     V = args.vocab_size
     if kind == "vqa":
@@ -99,6 +102,9 @@ def run_case(args, B, T, hw, kind, seed=0, stat_tol=1e-4):
     orc64 = copy.deepcopy(orc).double().train()
     orc.train()
     hip.train()
+    if tune:
+        n = hip.tune(img.to(dev()), ids.to(dev()), seg.to(dev()), mask.to(dev()))
+        assert n > 20, n
     out_ref = orc(img, ids, seg, mask)
     out = hip(img.to(dev()), ids.to(dev()), seg.to(dev()), mask.to(dev()))
     loss_ref = oracle_loss(kind, out_ref, tgt, B)
@@ -184,6 +190,22 @@ def test_full_config2_batch16_the_bench_shape():
              kind="mlm", stat_tol=TOL)
 
 
+def test_full_config2_batch16_tuned_launches_vs_oracle():
+    """the same, through the TUNED launcher: what bench.py times is what the oracle checks"""
+    run_case(O.make_args(hidden_dropout_prob=0.0, emb_dropout_prob=0.0, rf_dropout_prob=0.0), B=16, T=32, hw=224,
+             kind="mlm", stat_tol=TOL, tune=True)
+
+
+def test_full_config1_resnet152_transformer_vqa_head():
+    """BASELINE.json configs[0] (vqamed2019/train.py:117-160 construction): resnet152 at full depth + transformer + the VQA
+    head (masked mean pooling, classifier over the answer classes), batch 4, T 28 (the script's default), 224x224,
+    CrossEntropy-free comparison of logits plus the ASL loss / gradients; default and tuned launch choices"""
+    a = O.make_args(dataset="VQA-Med", vocab_size=1552, emb_vocab=30522, hidden_dropout_prob=0.0, emb_dropout_prob=0.0,
+                    rf_dropout_prob=0.0)
+    run_case(a, B=4, T=28, hw=224, kind="vqa", stat_tol=TOL)
+    run_case(a, B=4, T=28, hw=224, kind="vqa", stat_tol=TOL, tune=True)
+
+
 def test_full_config3_and_4_effnetv2m_realformer_mlm_supcon_224():
     """BASELINE.json configs[2] AND configs[3]: tf_efficientnetv2_m at full depth (57 blocks) + RealFormer, 224x224, T 32,
     vocab 30522 -- configs[2] is pretrain/roco_train.py (MLM head), configs[3] is pretrain/roco_supcon_train.py, the same
@@ -195,12 +217,24 @@ def test_full_config3_and_4_effnetv2m_realformer_mlm_supcon_224():
              kind="supcon", stat_tol=TOL)
 
 
+def test_full_config3_and_4_tuned_launches_vs_oracle():
+    run_case(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer", heads=8, supcon=True,
+                         hidden_dropout_prob=0.0, emb_dropout_prob=0.0, rf_dropout_prob=0.0), B=8, T=32, hw=224,
+             kind="supcon", stat_tol=TOL, tune=True)
+
+
 def test_full_config5_effnetv2m_realformer_vqa_asl_224():
     """BASELINE.json configs[4]: vqamed2019/train.py --loss=ASLSingleLabel, tf_efficientnetv2_m + RealFormer, VQA head
     (masked mean-pool) with 1552 answer classes, T 28 (the script's default), full depth and width, 224x224, batch 4"""
     run_case(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer", heads=8, dataset="VQA-Med",
                          vocab_size=1552, emb_vocab=30522, hidden_dropout_prob=0.0, emb_dropout_prob=0.0,
                          rf_dropout_prob=0.0), B=4, T=28, hw=224, kind="vqa", stat_tol=TOL)
+
+
+def test_full_config5_tuned_launches_vs_oracle():
+    run_case(O.make_args(cnn_encoder="tf_efficientnetv2_m", transformer_model="realformer", heads=8, dataset="VQA-Med",
+                         vocab_size=1552, emb_vocab=30522, hidden_dropout_prob=0.0, emb_dropout_prob=0.0,
+                         rf_dropout_prob=0.0), B=4, T=28, hw=224, kind="vqa", stat_tol=TOL, tune=True)
 
 
 def test_full_config5_one_image_batch():
@@ -257,31 +291,40 @@ def test_tuned_launch_choices_give_the_same_step(cfg):
         torch.cuda.synchronize()
         return logits.detach().clone(), float(loss), hip.flat_grads.detach().clone()
 
+    # control: the untuned step run three times.  Float atomics (tap means, split-K, statistics) make the summation order
+    # run-dependent, and train-mode BatchNorm at random init amplifies that; the per-tensor spread of these runs is the
+    # noise floor n0 of "the same arithmetic in another order"
     l0, loss0, g0 = step()
+    ctl = [step() for _ in range(2)]
     p_before, b_before = hip.flat_params.detach().clone(), hip._flat[1].clone()
     n = hip.tune(img, ids, seg, mask)
     assert n > 20, n
     assert torch.equal(hip.flat_params, p_before) and torch.equal(hip._flat[1], b_before)
     assert float(hip.flat_grads.abs().max()) == 0.0
     l1, loss1, g1 = step()
-    assert relerr(l1, l0) <= 1e-4, f"logits tuned vs untuned {relerr(l1, l0):.2e}"
+    ln0 = max(relerr(c[0], l0) for c in ctl)
+    assert relerr(l1, l0) <= max(1e-4, 3 * ln0), f"logits tuned vs untuned {relerr(l1, l0):.2e} (untuned run-to-run {ln0:.2e})"
     assert abs(loss1 - loss0) <= 5e-4 * abs(loss0), (loss1, loss0)
     # per parameter tensor, relative to that tensor's largest gradient -- floored at 1e-3 of the largest gradient of the
     # model: a bias in front of a BatchNorm (projection-BN beta, proj_k.bias) has an exact gradient of zero and what
-    # either run computes for it is rounding noise
-    worst = ("", 0.0)
+    # either run computes for it is rounding noise.  Bound: 3 x the tensor's own run-to-run spread n0 (floor 1e-4: a
+    # tensor whose three untuned runs happened to agree to the last bit still sees another summation order when tuned).
+    # A wrong tile / split variant shows up as an O(1) error of the tensors it touches.
     floor = 1e-3 * float(g0.abs().max())
+    bad, report = [], []
     for name, prm in hip.named_parameters():
-        o, k = prm.data_ptr() - hip.flat_params.data_ptr(), prm.numel()
-        a, b = g1[o // 4:o // 4 + k], g0[o // 4:o // 4 + k]
+        o, k = (prm.data_ptr() - hip.flat_params.data_ptr()) // 4, prm.numel()
+        b = g0[o:o + k]
         scale = max(float(b.abs().max()), floor)
-        e = float((a - b).abs().max()) / scale
-        if e > worst[1]:
-            worst = (name, e)
-    # (a wrong tile / split variant shows up as an O(1) error of the tensors it touches; the reordering noise of fp32
-    # sums through train-mode BatchNorms at random init reaches about 2e-2 of a tensor's largest gradient)
-    assert worst[1] <= 5e-2, f"gradient tuned vs untuned: {worst}"
-    assert relerr(g1, g0) <= 1e-3, f"all gradients tuned vs untuned {relerr(g1, g0):.2e}"
+        n0 = max(float((c[2][o:o + k] - b).abs().max()) for c in ctl) / scale
+        e = float((g1[o:o + k] - b).abs().max()) / scale
+        report.append((e, n0, name))
+        if e > max(3 * n0, 1e-4):
+            bad.append(f"{name}: tuned-vs-untuned {e:.2e}, untuned run-to-run {n0:.2e}")
+    report.sort(reverse=True)
+    print("largest tuned-vs-untuned differences (e, n0, tensor):", [(f"{e:.1e}", f"{n0:.1e}", nm) for e, n0, nm in report[:5]])
+    assert not bad, "gradients move more under tuning than between identical untuned runs: " + "; ".join(bad[:8])
+    assert relerr(g1, g0) <= max(1e-3, 3 * max(relerr(c[2], g0) for c in ctl)), f"all gradients tuned vs untuned {relerr(g1, g0):.2e}"
 
 
 @pytest.mark.parametrize("tag,tm,ds,supcon,cnn,relu", MODEL_CASES)
@@ -520,3 +563,42 @@ def test_grad_ready_ranges_partition_the_buffer():
         for lo, hi, snap in snaps:
             assert torch.equal(snap, hip.flat_grads[lo:hi]), (lo, hi)
         hip.set_grad_ready_hook(None)
+
+
+def test_grad_ready_event_orders_a_third_stream():
+    """What RCCL's stream does with an announced range, without RCCL: a THIRD stream that waits only on the `ready`
+    event of the announcement copies the range and then poisons it (NaN).  If the event really follows every writer of
+    the range -- the engine stream's own kernels and the side stream's weight gradients joined before the
+    announcement -- then (a) each copy equals the gradients of an undisturbed run and (b) the poison survives to the
+    end of backward everywhere (a kernel that still wrote into an announced range would leave finite values).  gloo
+    cannot show this: its CUDA path synchronises the producing stream on the host before it copies."""
+    for kw in (dict(resnet_layers=(2, 2, 14, 2), resnet_width=8), dict(cnn_encoder="tf_efficientnetv2_m", effnet_depth_div=3)):
+        args = mini_args(**kw)
+        _, hip = build_pair(args, seed=6)
+        img, ids, seg, mask, tgt = (t.to(dev()) for t in synth.roco_batch(2, 12, 32, vocab=50, seed=4))
+        hip.train()
+        mmvqa_amd.mlm_loss(hip(img, ids, seg, mask), tgt)[0].backward()
+        torch.cuda.synchronize()
+        want = hip.flat_grads.clone()
+        hip.flat_grads.zero_()
+        third = torch.cuda.Stream()
+        snaps = []
+
+        def hook(lo, hi, ready):
+            with torch.cuda.stream(third):
+                third.wait_event(ready)
+                snaps.append((lo, hi, hip.flat_grads[lo:hi].clone()))
+                hip.flat_grads[lo:hi].fill_(float("nan"))
+
+        hip.set_grad_ready_hook(hook, with_event=True)
+        mmvqa_amd.mlm_loss(hip(img, ids, seg, mask), tgt)[0].backward()
+        torch.cuda.synchronize()
+        hip.set_grad_ready_hook(None)
+        assert len(snaps) >= 4
+        assert bool(torch.isnan(hip.flat_grads).all()), "a kernel wrote into a gradient range after it was announced"
+        scale = float(want.abs().max())
+        for lo, hi, snap in snaps:
+            assert bool(torch.isfinite(snap).all()), (lo, hi)
+            err = float((snap - want[lo:hi]).abs().max()) / scale
+            assert err <= 1e-5, f"range [{lo}, {hi}) read through the ready event differs from the finished gradients: {err:.2e}"
+        hip.flat_grads.zero_()

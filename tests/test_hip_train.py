@@ -57,8 +57,11 @@ def test_resume_keeps_scheduler_wired(tmp_path):
     opt = mmvqa_amd.FusedAdam(model, lr=5e-2)
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(train._SchedShim(opt), patience=0, factor=0.1)
     ns = argparse.Namespace(save_dir=str(tmp_path), resume=True)
-    start = train.maybe_resume(ns, model, opt, sched)
+    start, kept = train.maybe_resume(ns, model, opt, sched, "mlm")
     assert start == 5 and opt.step_count == 30
+    assert kept["best"] < 10.0                                  # the best validation loss travels with the recorder
+    with pytest.raises(RuntimeError, match="written by the 'mlm' loop"):
+        train.maybe_resume(ns, model, opt, sched, "vqa")        # another loop's recorder in the same save_dir is refused
     assert opt.param_groups[0]["lr"] == pytest.approx(1e-3)     # the checkpoint's lr, not the constructor's
     assert float(opt.m.abs().sum()) > 0
     for _ in range(sched.patience + 1):                         # (patience/best come from the checkpoint)
@@ -69,3 +72,23 @@ def test_resume_keeps_scheduler_wired(tmp_path):
     opt.step()
     step = float((p0 - model.flat_params).abs().max())
     assert 0 < step <= 1.2e-4                                   # |dp| <= lr for Adam
+
+
+def test_eval_subcommand_writes_the_two_files(tmp_path):
+    """vqamed2019/eval.py:99-180 counterpart: checkpoint of a fine-tuning run -> test-set metrics + the two files"""
+    import csv
+    from mmvqa_amd import train
+    d = tmp_path / "ft"
+    train.main(["vqa", "--lr", "1e-3", "--batch_size", "8", "--loss", "ASLSingleLabel", "--num_classes", "11",
+                "--save_dir", str(d)] + MINI)
+    out = tmp_path / "out"
+    loss, acc, bleu = train.main(["eval", "--model_dir", str(d / "MLM" / "run.pt"), "--num_classes", "11", "--batch_size", "8",
+                                  "--test_samples", "20", "--save_dir", str(out)] + MINI)
+    assert loss == loss
+    assert set(acc) == {"total_acc", "binary_acc", "plane_acc", "organ_acc", "modality_acc", "abnorm_acc"}
+    assert set(bleu) == {k.replace("_acc", "_bleu") for k in acc}
+    rows = list(csv.reader(open(out / "run.pt_preds.csv")))
+    assert rows[0] == ["img_id", "question", "answer", "category", "mode", "preds", "decode_preds", "decode_ans"]
+    assert len(rows) == 21
+    res = open(out / "run.pt_res.txt").read().splitlines()
+    assert len(res) == 20 and res[0].startswith("synpic10000|")
