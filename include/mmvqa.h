@@ -36,6 +36,40 @@ typedef void* mmvqa_stream_t; /* hipStream_t */
 
 #define MMVQA_STAT_SLOTS 16
 
+/* BatchNorm coefficients folded inside the CONSUMING launch (training mode).
+ * The launches that produce a BatchNorm's input accumulate its per-channel sums into `stat`
+ * ([MMVQA_STAT_SLOTS][C][2] doubles, the first `slots` replicas in use: forward sum z / sum z^2, backward
+ * sum g / sum g*xhat).  A launch whose operand prologue applies that BatchNorm can derive the coefficients
+ * from the sums in its own setup phase, so that no coefficient launch (mmvqa_bn_coef_fwd / _bwd) sits between
+ * producer and consumer on the dependency chain.  With `publish` one workgroup of the launch also writes what
+ * the separate launch would have written: coefficients for later launches, running statistics with torch's
+ * momentum rule applied `reps` times (models/image_encoding.py:72-86 runs the backbone prefix 5 times),
+ * num_batches_tracked, and -- backward -- the gamma / beta gradients.  stat == NULL: no folding. */
+typedef struct mmvqa_bn_fold {
+  const double* stat;
+  int slots;          /* replicas of the sums that are in use (power of two, <= MMVQA_STAT_SLOTS) */
+  int bwd;            /* 0: -> scale, shift (and mean, invstd) ; 1: -> P, Q, R of dz = P*g + Q*z + R */
+  int publish;
+  int reps;
+  double count;       /* elements per channel */
+  double keep;        /* (1 - momentum)^reps */
+  float eps;
+  int reserved;
+  const float* gamma;
+  const float* beta;    /* forward */
+  const float* mean;    /* backward: the forward pass's batch mean / 1/sqrt(var+eps) */
+  const float* invstd;
+  float* out0;          /* publish: forward scale | backward P */
+  float* out1;          /*          forward shift | backward Q */
+  float* out2;          /*          forward mean  | backward R */
+  float* out3;          /*          forward invstd */
+  float* run_mean;
+  float* run_var;
+  long long* nbt;
+  float* dgamma;        /* backward publish: += sum g*xhat */
+  float* dbeta;         /*                   += sum g */
+} mmvqa_bn_fold;
+
 /* Descriptor of one implicit-GEMM launch (see mm-vqa_amd/csrc/igemm.hip for the field semantics).
  * Replaces: torch.nn.Conv2d / nn.Linear forward+backward as used by models/image_encoding.py:53-86,
  * models/transformer.py:13-15,45-48, models/realformer.py:13-27, models/mmbert.py:133-148. */
@@ -101,6 +135,17 @@ typedef struct mmvqa_gemm_desc {
                          tuner's choice when splitk <= 0): partial tiles go to the scratch and a second launch sums them
                          and applies the whole epilogue.  Needs splitk * M * N <= sk_ws_floats; one stream at a time. */
   long long sk_ws_floats;
+  mmvqa_bn_fold a_fold; /* optional: the coefficients of the A prologue (a_pro AFFINE_RELU: scale/shift; DZ: P/Q/R) come
+                           from raw sums instead of a_c0 / a_c1 / a_c2 (which may then be NULL) */
+  int stat_slots;       /* replicas the statistics epilogue (stat1 / stat2) spreads its sums over; 0 = MMVQA_STAT_SLOTS */
+  int persist;          /* > 0: persistent ("stream-K") launch of that many workgroups, each walking an equal share of the
+                           launch's K-tile iterations; tiles cut over several workgroups are completed by the workgroup
+                           that arrives last.  Plain-epilogue products only; an accumulating product (c_atomic) needs
+                           nothing else, any other needs sk_ws (partial tiles) and sk_cnt (tickets).  0 = one workgroup
+                           per tile (and split).  The launcher falls back to that form when a condition is not met. */
+  unsigned int* sk_cnt; /* persist: sk_cnt_n arrival tickets, ZERO before the first launch; every launch leaves them zero */
+  int sk_cnt_n;
+  int reserved0;
 } mmvqa_gemm_desc;
 
 /* Fused attention (models/transformer.py:19-30 and models/realformer.py:30-45). */
@@ -174,6 +219,11 @@ int mmvqa_bn_coef_bwd(mmvqa_stream_t s, const double* stat, int C, double count,
                       float* dgamma, float* dbeta);
 int mmvqa_bn_add_relu(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, const float* idn,
                       const float* id_sc, const float* id_sh, float* out, long rows, int C);
+/* the same block end, relu(bn3(z) + [bn_d](idn)), with the BatchNorm coefficients folded from their raw sums inside the
+ * launch (forward mmvqa_bn_fold; fd == NULL: the identity branch is added as it is) -- no coefficient launch between
+ * conv3 and the block end (models/image_encoding.py:72-86 via torchvision Bottleneck.forward) */
+int mmvqa_bn_add_relu_fold(mmvqa_stream_t s, const float* z, const mmvqa_bn_fold* f3, const float* idn,
+                           const mmvqa_bn_fold* fd, float* out, long rows, int C);
 int mmvqa_maxpool_fwd(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, float* out,
                       unsigned char* idx, int N, int H, int W, int C, int OH, int OW);
 int mmvqa_maxpool_bwd(mmvqa_stream_t s, const float* gp, const unsigned char* idx, const float* extra,
@@ -295,6 +345,10 @@ long long mmvqa_engine_buf_floats(const mmvqa_engine* e);
 long long mmvqa_engine_nbt_count(const mmvqa_engine* e);
 /* plan for a batch geometry; returns workspace bytes needed (0 on error) */
 size_t mmvqa_engine_plan(mmvqa_engine* e, int B, int T, int img_h, int img_w);
+/* Borrowed buffers of the following forward / backward calls.  Part of the WORKSPACE holds state that must survive
+ * between calls (tap-validity tables of the 3x3 weight gradients, the zeroed arrival tickets of persistent GEMM
+ * launches): the first forward after a bind puts it in place on that call's stream; the caller must not write to the
+ * workspace while it is bound (re-bind after any such write). */
 int mmvqa_engine_bind(mmvqa_engine* e, float* params, float* grads, float* bufs, long long* nbt, void* workspace,
                       size_t workspace_bytes);
 /* img fp32 NCHW [B,3,h,w]; ids/seg/mask int64 [B,T]; logits [rows][ld] (rows = B*T or B);

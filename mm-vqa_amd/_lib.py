@@ -22,6 +22,17 @@ EPI_PLAIN, EPI_TAP_FWD, EPI_TAP_BWD = 0, 1, 2
 STAT_SLOTS = 16
 
 
+class BnFold(C.Structure):
+    """mirror of mmvqa_bn_fold"""
+    _fields_ = [
+        ("stat", c_ptr), ("slots", C.c_int), ("bwd", C.c_int), ("publish", C.c_int), ("reps", C.c_int),
+        ("count", C.c_double), ("keep", C.c_double), ("eps", C.c_float), ("reserved", C.c_int),
+        ("gamma", c_ptr), ("beta", c_ptr), ("mean", c_ptr), ("invstd", c_ptr),
+        ("out0", c_ptr), ("out1", c_ptr), ("out2", c_ptr), ("out3", c_ptr),
+        ("run_mean", c_ptr), ("run_var", c_ptr), ("nbt", c_ptr), ("dgamma", c_ptr), ("dbeta", c_ptr),
+    ]
+
+
 class GemmDesc(C.Structure):
     """mirror of mmvqa_gemm_desc"""
     _fields_ = [
@@ -42,6 +53,8 @@ class GemmDesc(C.Structure):
         ("stat2", c_ptr), ("Z2", c_ptr), ("z2_ld", C.c_int), ("mean2", c_ptr), ("invstd2", c_ptr),
         ("colsum", c_ptr), ("gate", c_ptr), ("gate_hw", C.c_int), ("mk_mode", C.c_int), ("pixmask", c_ptr),
         ("sk_ws", c_ptr), ("sk_ws_floats", C.c_longlong),
+        ("a_fold", BnFold), ("stat_slots", C.c_int), ("persist", C.c_int), ("sk_cnt", c_ptr), ("sk_cnt_n", C.c_int),
+        ("reserved0", C.c_int),
     ]
 
 
@@ -93,6 +106,7 @@ SIGNATURES = {
     "mmvqa_bn_coef_fwd": (_i, [_P, _P, _i, _d, _f, _P, _P, _P, _P, _P, _f, _i, _i, _P, _P, _P, _P]),
     "mmvqa_bn_coef_bwd": (_i, [_P, _P, _i, _d, _P, _P, _P, _i, _P, _P, _P, _P, _P]),
     "mmvqa_bn_add_relu": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _l, _i]),
+    "mmvqa_bn_add_relu_fold": (_i, [_P, _P, C.POINTER(BnFold), _P, C.POINTER(BnFold), _P, _l, _i]),
     "mmvqa_maxpool_fwd": (_i, [_P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i]),
     "mmvqa_maxpool_bwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i]),
     "mmvqa_layernorm_fwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _f]),

@@ -34,8 +34,8 @@ static int check_gemm(const mmvqa_gemm_desc* d, int kind, int nchw) {
     if (kind != KIND_FWD && (d->N & 3) && kind == KIND_DGRAD)
       return mmvqa_set_error(MMVQA_ERR_ARG, "igemm dgrad: N=%d must be a multiple of 4", d->N);
   }
-  if (d->a_pro == PRO_DZ && (!d->A2 || !d->a_c0 || !d->a_c1 || !d->a_c2))
-    return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: PRO_DZ needs A2 and three coefficient arrays");
+  if (d->a_pro == PRO_DZ && (!d->A2 || (!d->a_fold.stat && (!d->a_c0 || !d->a_c1 || !d->a_c2))))
+    return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: PRO_DZ needs A2 and three coefficient arrays (or a_fold)");
   if (d->g_SH <= 0 || d->g_SW <= 0 || d->g_OH <= 0 || d->g_OW <= 0 || d->g_Cs <= 0)
     return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: gather geometry not set");
   return MMVQA_OK;
@@ -68,6 +68,11 @@ int mmvqa_bn_coef_bwd(mmvqa_stream_t s, const double* stat, int C, double count,
                       const float* mean, const float* invstd, int training, float* P, float* Q, float* R,
                       float* dgamma, float* dbeta) {
   return k_bn_coef_bwd(ST(s), stat, C, count, gamma, mean, invstd, training, P, Q, R, dgamma, dbeta);
+}
+int mmvqa_bn_add_relu_fold(mmvqa_stream_t s, const float* z, const mmvqa_bn_fold* f3, const float* idn,
+                           const mmvqa_bn_fold* fd, float* out, long rows, int C) {
+  if (!z || !idn || !out || !f3) return mmvqa_set_error(MMVQA_ERR_ARG, "bn_add_relu_fold: null operand");
+  return k_bn_add_relu_fold(ST(s), z, f3, idn, fd, out, rows, C);
 }
 int mmvqa_bn_add_relu(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, const float* idn,
                       const float* id_sc, const float* id_sh, float* out, long rows, int C) {
@@ -251,7 +256,7 @@ int mmvqa_engine_bind(mmvqa_engine* e, float* params, float* grads, float* bufs,
     return mmvqa_set_error(MMVQA_ERR_ARG, "bind: buffers must be 16-byte aligned");
   e->params = params; e->grads = grads; e->bufs = bufs; e->nbt = nbt;
   e->ws = reinterpret_cast<float*>(workspace);
-  e->pixmask_built.clear();   // tables live in the (new) workspace: rebuilt on first use
+  e->ws_ready = false;        // tap-validity tables and tickets live in the (new) workspace: put in place by the next forward
   e->bound = true;
   e->img = nullptr;
   return MMVQA_OK;

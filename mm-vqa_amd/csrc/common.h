@@ -127,6 +127,65 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// --------------------------------------------------------------------------- BatchNorm coefficients from raw sums
+// (mmvqa_bn_fold in the ABI).  The arithmetic is that of bn_coef_fwd_kernel / bn_coef_bwd_kernel (elementwise.hip):
+// sums in double over the replicas, torchvision BatchNorm2d semantics (biased variance for the batch, unbiased for the
+// running estimate, momentum applied `reps` times at once).
+typedef mmvqa_bn_fold BnFold;
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// sums of channel c over the replicas in use: every load is issued before the first add (one memory round trip)
+__device__ __forceinline__ void bn_fold_sums(const double* __restrict__ stat, int slots, int C, int c, double& s0,
+                                             double& s1) {
+  f64x2 v[MMVQA_STAT_SLOTS];
+#pragma unroll
+  for (int k = 0; k < MMVQA_STAT_SLOTS; ++k) {
+    v[k] = f64x2{0.0, 0.0};
+    if (k < slots) v[k] = *reinterpret_cast<const f64x2*>(stat + ((size_t)k * C + c) * 2);
+  }
+  s0 = 0.0; s1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < MMVQA_STAT_SLOTS; ++k) { s0 += v[k][0]; s1 += v[k][1]; }
+}
+
+// forward: (sum z, sum z^2) -> y = z*scale + shift; `pub`: this thread writes channel c's published values
+__device__ __forceinline__ void bn_fold_fwd(const BnFold& f, int C, int c, bool pub, float& scale, float& shift) {
+  double s, ss;
+  bn_fold_sums(f.stat, f.slots, C, c, s, ss);
+  const double mu = s / f.count;
+  double var = ss / f.count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mu;
+  const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+  scale = f.gamma[c] * invstd;
+  shift = f.beta[c] - mean * scale;
+  if (pub) {
+    f.out0[c] = scale; f.out1[c] = shift; f.out2[c] = mean; f.out3[c] = invstd;
+    if (f.run_mean) {
+      const double unb = f.count > 1.0 ? var * (f.count / (f.count - 1.0)) : var;
+      f.run_mean[c] = (float)(f.keep * (double)f.run_mean[c] + (1.0 - f.keep) * mu);
+      f.run_var[c] = (float)(f.keep * (double)f.run_var[c] + (1.0 - f.keep) * unb);
+    }
+  }
+}
+
+// backward: (sum g, sum g*xhat) -> dz = P*g + Q*z + R ; published: P, Q, R and dgamma += sum g*xhat, dbeta += sum g
+__device__ __forceinline__ void bn_fold_bwd(const BnFold& f, int C, int c, bool pub, float& P, float& Q, float& R) {
+  double sg, sgx;
+  bn_fold_sums(f.stat, f.slots, C, c, sg, sgx);
+  const double is = (double)f.invstd[c];
+  const double p = (double)f.gamma[c] * is;
+  const double c1 = sg / f.count, c2 = sgx / f.count;
+  P = (float)p;
+  Q = (float)(-p * c2 * is);
+  R = (float)(p * (c2 * is * (double)f.mean[c] - c1));
+  if (pub) {
+    f.out0[c] = P; f.out1[c] = Q; f.out2[c] = R;
+    f.dgamma[c] += (float)sgx;
+    f.dbeta[c] += (float)sg;
+  }
+}
+
 // --------------------------------------------------------------------------- host side
 int mmvqa_set_error(int code, const char* fmt, ...);
 #define MMVQA_OK 0

@@ -3,6 +3,8 @@
 // SupCon, L2-normalise, Adam.  All use 16-byte accesses along the contiguous axis and
 // 64-lane wave reductions; per-channel sums are kept in double and spread over
 // MMVQA_STAT_SLOTS replicas to avoid same-address atomic serialisation.
+#include <cstring>
+
 #include "common.h"
 
 static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
@@ -983,6 +985,78 @@ int k_bn_coef_fwd(hipStream_t st, const double* stat, int C, double count, float
   hipLaunchKernelGGL(bn_coef_fwd_kernel, dim3(cdiv_i(C, 16)), dim3(256), 0, st, stat, C, count, eps, gamma, beta,
                      run_mean, run_var, nbt, pow(1.0 - (double)momentum, (double)reps), reps, training, scale, shift,
                      mean, invstd);   // (1 - momentum)^reps on the host: a double pow() per thread was most of the kernel's math
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+// Block end with the coefficients of bn3 (and of the downsample BatchNorm) folded from their raw sums (mmvqa_bn_fold):
+// no coefficient launch between conv3 and this kernel.  One workgroup = 64 channels x `rpw` rows; 64 (+64) threads fold
+// one channel each into LDS; the workgroups of row block 0 publish scale / shift / mean / invstd / running statistics.
+__global__ __launch_bounds__(256) void bn_add_relu_fold_kernel(const float* __restrict__ z, const BnFold f3,
+                                                               const float* __restrict__ idn, const BnFold fd, int has_d,
+                                                               float* __restrict__ out, long rows, int C, int rpw) {
+  __shared__ float cs[4][64];
+  const int tid = threadIdx.x, c0 = blockIdx.y * 64;
+  const bool pub = blockIdx.x == 0;
+  if (tid < 64) {
+    float a = 0.f, b = 0.f;
+    if (c0 + tid < C) bn_fold_fwd(f3, C, c0 + tid, pub && f3.publish, a, b);
+    cs[0][tid] = a; cs[1][tid] = b;
+  } else if (tid < 128) {
+    float a = 1.f, b = 0.f;
+    if (has_d && c0 + tid - 64 < C) bn_fold_fwd(fd, C, c0 + tid - 64, pub && fd.publish, a, b);
+    cs[2][tid - 64] = a; cs[3][tid - 64] = b;
+  }
+  if (pub && blockIdx.y == 0) {
+    if (tid == 0 && f3.publish && f3.nbt) *f3.nbt += f3.reps;
+    if (tid == 64 && has_d && fd.publish && fd.nbt) *fd.nbt += fd.reps;
+  }
+  __syncthreads();
+  const int q = tid & 15, rl = tid >> 4;
+  const int c = c0 + q * 4;
+  if (c >= C) return;
+  const f32x4 s3 = *reinterpret_cast<const f32x4*>(&cs[0][q * 4]), b3 = *reinterpret_cast<const f32x4*>(&cs[1][q * 4]);
+  const f32x4 sd = *reinterpret_cast<const f32x4*>(&cs[2][q * 4]), bd = *reinterpret_cast<const f32x4*>(&cs[3][q * 4]);
+  const long r0 = (long)blockIdx.x * rpw, r1 = r0 + rpw < rows ? r0 + rpw : rows;
+  for (long r = r0 + rl; r < r1; r += 32) {
+    const long i0 = r * C + c, i1 = (r + 16) * C + c;
+    const bool two = r + 16 < r1;
+    const f32x4 z0 = *reinterpret_cast<const f32x4*>(z + i0), d0 = *reinterpret_cast<const f32x4*>(idn + i0);
+    f32x4 z1 = z0, d1 = d0;
+    if (two) { z1 = *reinterpret_cast<const f32x4*>(z + i1); d1 = *reinterpret_cast<const f32x4*>(idn + i1); }
+    f32x4 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t0 = z0[j] * s3[j] + b3[j] + (d0[j] * sd[j] + bd[j]);
+      const float t1 = z1[j] * s3[j] + b3[j] + (d1[j] * sd[j] + bd[j]);
+      o0[j] = t0 > 0.f ? t0 : 0.f;
+      o1[j] = t1 > 0.f ? t1 : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(out + i0) = o0;
+    if (two) *reinterpret_cast<f32x4*>(out + i1) = o1;
+  }
+}
+
+int k_bn_add_relu_fold(hipStream_t st, const float* z, const mmvqa_bn_fold* f3, const float* idn, const mmvqa_bn_fold* fd,
+                       float* out, long rows, int C) {
+  if (C % 4 != 0 || !f3 || !f3->stat || f3->bwd || (fd && (!fd->stat || fd->bwd)))
+    return mmvqa_set_error(MMVQA_ERR_ARG, "bn_add_relu_fold: C=%d must be a multiple of 4 and the folds forward ones", C);
+  const int cb = cdiv_i(C, 64);
+  int rpw = 32;
+  while ((long)cdiv_i(rows, rpw) * cb > 4096 && rpw < 256) rpw *= 2;
+  mmvqa_bn_fold none;
+  memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(bn_add_relu_fold_kernel, dim3(cdiv_i(rows, rpw), cb), dim3(256), 0, st, z, *f3, idn, fd ? *fd : none,
+                     fd ? 1 : 0, out, rows, C, rpw);
+  KERNEL_CHECK_RET();
+  return MMVQA_OK;
+}
+
+int k_bn_coef_fwd_keep(hipStream_t st, const double* stat, int C, double count, float eps, const float* gamma,
+                       const float* beta, float* run_mean, float* run_var, long long* nbt, double keep, int reps,
+                       int training, float* scale, float* shift, float* mean, float* invstd) {
+  hipLaunchKernelGGL(bn_coef_fwd_kernel, dim3(cdiv_i(C, 16)), dim3(256), 0, st, stat, C, count, eps, gamma, beta,
+                     run_mean, run_var, nbt, keep, reps, training, scale, shift, mean, invstd);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }

@@ -248,6 +248,16 @@ struct Arena {
   }
 };
 
+// replicas of a folded BatchNorm's sums: every consumer workgroup reads slots x C x 16 bytes in its setup phase, every
+// producer workgroup adds one value per channel and sum to ONE replica -- few replicas for the consumers' sake, enough
+// of them that a replica does not collect more than a few dozen same-address atomics
+int fold_slots(double rows) {
+  static const int forced = getenv("MMVQA_BN_SLOTS") ? atoi(getenv("MMVQA_BN_SLOTS")) : 0;
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) return forced;
+  const double row_tiles = rows / 64.0;
+  return row_tiles >= 32.0 ? 4 : (row_tiles >= 8.0 ? 2 : 1);
+}
+
 void plan_bn(Arena& a, BNRef& bn, double count) {
   bn.count = count;
   const size_t C = bn.C;
@@ -266,7 +276,7 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
     return 0;
   }
   e->B = B; e->T = T; e->IH = IH; e->IW = IW;
-  e->pixmask_off.clear(); e->pixmask_built.clear();
+  e->pixmask_off.clear(); e->ws_ready = false;
   Arena a;
   const int H = d.hidden;
   const size_t M = (size_t)B * T;
@@ -345,7 +355,8 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
     if (blk.c2.stride == 1) {   // per-pixel tap-validity table of the 3x3 weight gradient: one per geometry, in the workspace
       char key[96];
       snprintf(key, sizeof(key), "%d,%d,%d,%d,%d", B, blk.OH, blk.OW, blk.c2.KH, blk.c2.pad);
-      if (!e->pixmask_off.count(key)) e->pixmask_off[key] = a.f(Mout);
+      if (!e->pixmask_off.count(key))
+        e->pixmask_off[key] = mmvqa_engine::PixGeom{B, blk.OH, blk.OW, h, wd, blk.c2.KH, blk.c2.stride, blk.c2.pad, a.f(Mout)};
     }
     blk.z2 = a.f(Mout * blk.c2.Cout);
     blk.z3 = a.f(Mout * blk.c3.Cout);
@@ -354,6 +365,10 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
     plan_bn(a, blk.b2, (double)Mout);
     plan_bn(a, blk.b3, (double)Mout);
     if (blk.has_ds) { blk.zd = a.f(Mout * blk.cd.Cout); plan_bn(a, blk.bd, (double)Mout); }
+    if (e->bn_fold) {
+      blk.b1.slots = fold_slots((double)Min);
+      blk.b2.slots = blk.b3.slots = blk.bd.slots = fold_slots((double)Mout);
+    }
     max_io = std::max(max_io, std::max(Min * blk.c1.Cin, Mout * blk.c3.Cout));
     max_mid = std::max(max_mid, std::max(Min * blk.c1.Cout, Mout * blk.c2.Cout));
     h = blk.OH; wd = blk.OW;
@@ -373,6 +388,7 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
   }
   e->vis = a.f((size_t)5 * B * H);
   for (int i = 0; i < 2; ++i) e->sk_ws[i] = a.f(SK_WS_FLOATS);   // split-K partial tiles (main / side stream)
+  for (int i = 0; i < 2; ++i) e->sk_cnt[i] = a.f(SK_CNT_N);      // arrival tickets of persistent launches
   e->dvis = a.f((size_t)5 * B * H);
   e->du = a.f(max_tapM * H);
   for (int i = 0; i < 3; ++i) e->gbuf[i] = a.f(max_io);
@@ -480,8 +496,11 @@ static GemmParams gp_linear_geom() {
 static void set_sk(mmvqa_engine* e, hipStream_t st, GemmParams& g) {
   static const bool off = getenv("MMVQA_NO_SK_WS") != nullptr;   // A/B switch: no K split of forward / data-gradient products
   if (off) return;
-  g.sk_ws = WS(e->sk_ws[(e->side && st == e->side) ? 1 : 0]);
+  const int which = (e->side && st == e->side) ? 1 : 0;
+  g.sk_ws = WS(e->sk_ws[which]);
   g.sk_ws_floats = (long long)SK_WS_FLOATS;
+  g.sk_cnt = reinterpret_cast<unsigned int*>(WS(e->sk_cnt[which]));
+  g.sk_cnt_n = SK_CNT_N;
 }
 
 struct EpiOpt {
@@ -495,7 +514,7 @@ static void apply_epi(mmvqa_engine* e, GemmParams& g, const EpiOpt& o) {
   g.R = o.R; g.r_ld = o.r_ld;
   g.Mk = o.Mk; g.mk_ld = o.mk_ld; g.mk_s = o.mk_s; g.mk_b = o.mk_b; g.mk_mode = o.mk_mode;
   if (o.st1) {
-    g.stat1 = stat_ptr(e, o.st1->stat_b); g.stat_bwd = 1;
+    g.stat1 = stat_ptr(e, o.st1->stat_b); g.stat_bwd = 1; g.stat_slots = o.st1->slots;
     g.Z1 = o.Z1; g.z1_ld = o.st1->C; g.mean1 = WS(o.st1->mean); g.invstd1 = WS(o.st1->invstd);
   }
   if (o.st2) {
@@ -595,6 +614,27 @@ static int bn_coef_bwd(mmvqa_engine* e, hipStream_t st, BNRef& bn) {
   return MMVQA_OK;
 }
 
+// The ResNet path in training mode folds the BatchNorm coefficients inside the launches that consume them
+// (mmvqa_bn_fold: no coefficient launch between a convolution and its consumer on the dependency chain).
+static inline bool folding(const mmvqa_engine* e) { return e->bn_fold && e->training && e->d.cnn == 0; }
+
+static void set_fold_fwd(mmvqa_engine* e, mmvqa_bn_fold& f, BNRef& bn) {
+  memset(&f, 0, sizeof(f));
+  f.stat = stat_ptr(e, bn.stat_f); f.slots = bn.slots; f.bwd = 0; f.publish = 1; f.reps = bn.reps;
+  f.count = bn.count; f.keep = pow(1.0 - (double)0.1f, (double)bn.reps); f.eps = bn.eps;
+  f.gamma = PRM(bn.gamma); f.beta = PRM(bn.beta);
+  f.out0 = WS(bn.scale); f.out1 = WS(bn.shift); f.out2 = WS(bn.mean); f.out3 = WS(bn.invstd);
+  f.run_mean = e->bufs + bn.rmean; f.run_var = e->bufs + bn.rvar; f.nbt = e->nbt + bn.nbt;
+}
+static void set_fold_bwd(mmvqa_engine* e, mmvqa_bn_fold& f, const BNRef& bn, bool publish) {
+  memset(&f, 0, sizeof(f));
+  f.stat = stat_ptr(e, bn.stat_b); f.slots = bn.slots; f.bwd = 1; f.publish = publish ? 1 : 0; f.reps = bn.reps;
+  f.count = bn.count; f.keep = 1.0; f.eps = bn.eps;
+  f.gamma = PRM(bn.gamma); f.mean = WS(bn.mean); f.invstd = WS(bn.invstd);
+  f.out0 = WS(bn.P); f.out1 = WS(bn.Q); f.out2 = WS(bn.R);
+  f.dgamma = GRD(bn.gamma); f.dbeta = GRD(bn.beta);
+}
+
 // z = conv(x) with x optionally = relu(bn_in(x_raw)); accumulates the batch statistics of z
 static int conv_fwd(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const float* x, const BNRef* bn_in, int N,
                     int H, int W, int OH, int OW, float* z, BNRef& bn_out) {
@@ -602,14 +642,18 @@ static int conv_fwd(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const flo
   memset(&g, 0, sizeof(g));
   g.M = N * OH * OW; g.N = c.Cout; g.K = c.KH * c.KH * c.Cin;
   g.A = x; g.a_ld = c.Cin;
-  if (bn_in) { g.a_pro = PRO_AFFINE_RELU; g.a_c0 = WS(bn_in->scale); g.a_c1 = WS(bn_in->shift); }
+  if (bn_in) {
+    g.a_pro = PRO_AFFINE_RELU; g.a_c0 = WS(bn_in->scale); g.a_c1 = WS(bn_in->shift);
+    if (folding(e)) set_fold_fwd(e, g.a_fold, *const_cast<BNRef*>(bn_in));   // this launch is bn_in's first consumer
+  }
   g.g_SH = H; g.g_SW = W; g.g_Cs = c.Cin; g.g_OH = OH; g.g_OW = OW;
   conv_geom(g, c, H, W, OH, OW);
   g.B = PRM(c.w); g.b_ld = g.K;
   g.C = z; g.c_ld = c.Cout;
-  if (e->training) { g.stat1 = stat_ptr(e, bn_out.stat_f); g.stat_bwd = 0; }
+  if (e->training) { g.stat1 = stat_ptr(e, bn_out.stat_f); g.stat_bwd = 0; g.stat_slots = bn_out.slots; }
   set_sk(e, st, g);
   RUN(PROF_IGEMM, 2.0 * g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
+  if (folding(e)) return MMVQA_OK;   // bn_out's coefficients: folded by its consumer (next convolution / block end)
   return bn_coef_fwd(e, st, bn_out);
 }
 
@@ -621,6 +665,7 @@ static int conv_wgrad(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const f
   g.M = c.Cout; g.N = c.KH * c.KH * c.Cin; g.K = N * OH * OW;
   g.A = G; g.A2 = z; g.a_ld = c.Cout; g.a_pro = PRO_DZ;
   g.a_c0 = WS(bn_out.P); g.a_c1 = WS(bn_out.Q); g.a_c2 = WS(bn_out.R);
+  if (folding(e)) set_fold_bwd(e, g.a_fold, bn_out, false);   // (the data gradient of the same BatchNorm publishes)
   g.B = x; g.b_ld = c.Cin;
   if (bn_in) { g.b_pro = PRO_AFFINE_RELU; g.b_c0 = WS(bn_in->scale); g.b_c1 = WS(bn_in->shift); }
   g.g_SH = H; g.g_SW = W; g.g_Cs = c.Cin; g.g_OH = OH; g.g_OW = OW;
@@ -631,14 +676,7 @@ static int conv_wgrad(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const f
     char key[96];
     snprintf(key, sizeof(key), "%d,%d,%d,%d,%d", N, OH, OW, c.KH, c.pad);
     auto it = e->pixmask_off.find(key);
-    if (it != e->pixmask_off.end()) {
-      int* tab = reinterpret_cast<int*>(WS(it->second));
-      if (!e->pixmask_built[key]) {
-        TRY(k_pixmask(st, tab, N, OH, OW, H, W, c.KH, c.KH, c.stride, c.pad));
-        e->pixmask_built[key] = true;
-      }
-      g.pixmask = tab;
-    }
+    if (it != e->pixmask_off.end()) g.pixmask = reinterpret_cast<int*>(WS(it->second.off));   // built by prepare_workspace()
   }
   RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_WGRAD, 0, 0, st));
   return MMVQA_OK;
@@ -652,6 +690,7 @@ static int conv_dgrad(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const f
   g.M = N * H * W; g.N = c.Cin; g.K = c.KH * c.KH * c.Cout;
   g.A = G; g.A2 = z; g.a_ld = c.Cout; g.a_pro = PRO_DZ;
   g.a_c0 = WS(bn_out.P); g.a_c1 = WS(bn_out.Q); g.a_c2 = WS(bn_out.R);
+  if (folding(e)) set_fold_bwd(e, g.a_fold, bn_out, true);
   g.g_SH = OH; g.g_SW = OW; g.g_Cs = c.Cout; g.g_OH = H; g.g_OW = W;
   conv_geom(g, c, H, W, OH, OW);
   g.B = PRM(c.w); g.b_ld = c.KH * c.KH * c.Cin; g.b_tapstride = c.Cin;
@@ -831,7 +870,13 @@ static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
     TRY(conv_fwd(e, st, b.c2, WS(b.z1), &b.b1, B, b.H, b.W, b.OH, b.OW, WS(b.z2), b.b2));
     TRY(conv_fwd(e, st, b.c3, WS(b.z2), &b.b2, B, b.OH, b.OW, b.OH, b.OW, WS(b.z3), b.b3));
     const long rows = (long)B * b.OH * b.OW;
-    if (b.has_ds) {
+    if (folding(e)) {
+      mmvqa_bn_fold f3, fd;
+      set_fold_fwd(e, f3, b.b3);
+      if (b.has_ds) { sc.need(ev_ds); set_fold_fwd(e, fd, b.bd); }
+      RUN(PROF_OTHER, 0, k_bn_add_relu_fold(st, WS(b.z3), &f3, b.has_ds ? WS(b.zd) : x, b.has_ds ? &fd : nullptr,
+                                            WS(b.out), rows, b.c3.Cout));
+    } else if (b.has_ds) {
       sc.need(ev_ds);
       RUN(PROF_OTHER, 0, k_bn_add_relu(st, WS(b.z3), WS(b.b3.scale), WS(b.b3.shift), WS(b.zd), WS(b.bd.scale),
                                        WS(b.bd.shift), WS(b.out), rows, b.c3.Cout));
@@ -891,7 +936,7 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
       if (i - 1 == e->layer_end[l]) { extra = WS(e->tapgrad[3 - l]); ev_extra = ev_tap[3 - l]; }
     hipEvent_t evG = nullptr;   // side readers of this block's G
     // conv3 / bn3
-    TRY(bn_coef_bwd(e, st, b.b3));
+    if (!folding(e)) TRY(bn_coef_bwd(e, st, b.b3));
     sc.fork();
     TRY(conv_wgrad(e, sd, b.c3, G, WS(b.z3), b.b3, WS(b.z2), &b.b2, B, b.OH, b.OW, b.OH, b.OW));
     evG = sc.mark();
@@ -903,7 +948,7 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
       TRY(conv_dgrad(e, st, b.c3, G, WS(b.z3), b.b3, B, b.OH, b.OW, b.OH, b.OW, WS(e->g2buf), o));
     }
     // conv2 / bn2
-    TRY(bn_coef_bwd(e, st, b.b2));
+    if (!folding(e)) TRY(bn_coef_bwd(e, st, b.b2));
     sc.fork();
     TRY(conv_wgrad(e, sd, b.c2, WS(e->g2buf), WS(b.z2), b.b2, WS(b.z1), &b.b1, B, b.H, b.W, b.OH, b.OW));
     ev_g2 = sc.mark();
@@ -915,7 +960,7 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
       TRY(conv_dgrad(e, st, b.c2, WS(e->g2buf), WS(b.z2), b.b2, B, b.H, b.W, b.OH, b.OW, WS(e->g1buf), o));
     }
     // conv1 / bn1
-    TRY(bn_coef_bwd(e, st, b.b1));
+    if (!folding(e)) TRY(bn_coef_bwd(e, st, b.b1));
     sc.fork();
     TRY(conv_wgrad(e, sd, b.c1, WS(e->g1buf), WS(b.z1), b.b1, x, nullptr, B, b.H, b.W, b.H, b.W));
     ev_g1 = sc.mark();
@@ -928,7 +973,7 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
       if (pb.has_ds) { o.st2 = &pb.bd; o.Z2 = WS(pb.zd); }
     }
     if (b.has_ds) {
-      TRY(bn_coef_bwd(e, st, b.bd));
+      if (!folding(e)) TRY(bn_coef_bwd(e, st, b.bd));
       sc.fork();
       TRY(conv_wgrad(e, sd, b.cd, G, WS(b.zd), b.bd, x, nullptr, B, b.H, b.W, b.OH, b.OW));
       evG = sc.mark();
@@ -1436,9 +1481,24 @@ static int heads_backward(mmvqa_engine* e, hipStream_t st, const float* h, const
 }
 
 // --------------------------------------------------------------------------- whole model
+// State that lives in the caller's workspace ACROSS calls (mmvqa.h, mmvqa_engine_bind): the tap-validity tables of the
+// 3x3 weight gradients and the (zero) arrival tickets of the persistent launches.  Put in place on the caller's stream
+// by the first forward after a bind, i.e. before the side stream exists for that workspace.
+static int prepare_workspace(mmvqa_engine* e, hipStream_t st) {
+  if (e->ws_ready) return MMVQA_OK;
+  for (auto& kv : e->pixmask_off) {
+    const mmvqa_engine::PixGeom& q = kv.second;
+    TRY(k_pixmask(st, reinterpret_cast<int*>(WS(q.off)), q.N, q.OH, q.OW, q.H, q.W, q.KH, q.KH, q.stride, q.pad));
+  }
+  for (int i = 0; i < 2; ++i) HIP_CHECK_RET(hipMemsetAsync(WS(e->sk_cnt[i]), 0, SK_CNT_N * sizeof(unsigned int), st));
+  e->ws_ready = true;
+  return MMVQA_OK;
+}
+
 int engine_forward(mmvqa_engine* e, hipStream_t st, const float* img, const long long* ids, const long long* seg,
                    const long long* mask, float* logits, int logits_ld, float* feat, int training, uint32_t seed) {
   if (!e->planned || !e->bound) return mmvqa_set_error(MMVQA_ERR_STATE, "engine_forward: plan/bind first");
+  TRY(prepare_workspace(e, st));
   const mmvqa_model_desc& d = e->d;
   if (logits_ld < d.n_classes || (logits_ld & 3))
     return mmvqa_set_error(MMVQA_ERR_ARG, "engine_forward: logits_ld=%d must be >= n_classes and %%4==0", logits_ld);
@@ -1496,6 +1556,7 @@ int engine_create(const mmvqa_model_desc* desc, mmvqa_engine** out) {
   mmvqa_engine* e = new mmvqa_engine();
   e->d = d;
   if (getenv("MMVQA_NO_SIDE_STREAM")) e->use_side = 0;   // A/B switch: everything on the caller's stream
+  if (getenv("MMVQA_NO_BN_FOLD")) e->bn_fold = 0;        // A/B switch: separate BatchNorm coefficient launches everywhere
   memset(e->prof_launch, 0, sizeof(e->prof_launch));
   memset(e->prof_ms, 0, sizeof(e->prof_ms));
   memset(e->prof_flops, 0, sizeof(e->prof_flops));

@@ -18,6 +18,7 @@ struct TensorSpec {
 
 struct BNRef {
   int C = 0, reps = 1;
+  int slots = MMVQA_STAT_SLOTS;   // replicas of the per-channel sums its producers spread their atomics over
   float eps = 1e-5f;
   long long gamma = 0, beta = 0, rmean = 0, rvar = 0, nbt = 0;
   // plan (offsets into workspace, floats; stats in doubles from ws_d)
@@ -89,6 +90,7 @@ enum { REG_BACKBONE = 0, REG_TAP = 1, REG_QKV = 2, REG_ATTN = 3, REG_ENC = 4, RE
        REG_BNCOEF = 7, REG_N = 8 };
 
 constexpr size_t SK_WS_FLOATS = (size_t)8 << 20;   // 32 MB: 8 splits of a 224-tile (64x64) product
+constexpr int SK_CNT_N = 16384;                    // tiles a persistent launch may have (one arrival ticket each)
 
 struct mmvqa_engine {
   mmvqa_model_desc d;
@@ -143,9 +145,14 @@ struct mmvqa_engine {
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
   int use_side = 1;
-  // ---- per-geometry tap-validity tables of the 3x3 weight gradients (mmvqa_gemm_desc.pixmask), built on first use
-  std::map<std::string, size_t> pixmask_off;   // workspace offset per geometry (planned)
-  std::map<std::string, bool> pixmask_built;   // filled on first use after every bind (the workspace is the caller's)
+  int bn_fold = 1;   // ResNet, training: BatchNorm coefficients are folded inside the consuming launches (mmvqa_bn_fold)
+  // ---- per-geometry tap-validity tables of the 3x3 weight gradients (mmvqa_gemm_desc.pixmask): planned into the
+  // workspace, ALL built on the caller's stream at the start of the first forward after every bind -- before either
+  // stream can launch a weight gradient (the workspace is the caller's: see mmvqa_engine_bind in mmvqa.h)
+  struct PixGeom { int N, OH, OW, H, W, KH, stride, pad; size_t off; };
+  std::map<std::string, PixGeom> pixmask_off;
+  bool ws_ready = false;                        // persistent workspace state (tables, tickets) is in place
+  size_t sk_cnt[2] = {0, 0};                    // arrival tickets of persistent launches (main / side stream)
   // ---- gradient-ready notifications (data-parallel overlap): called on the host right after the kernels that
   // complete grads[lo, hi) have been enqueued and the main stream has been ordered behind them
   void (*grad_cb)(void* user, long long lo, long long hi) = nullptr;

@@ -38,6 +38,17 @@ struct GemmAux {
   int fast;   // 0: general loaders | 1: uniform-tap loaders | 2: uniform-tap loaders with a halo mask (host-decided)
   int stagger;   // 8-wave variant: the second wave group runs its VALU/LDS-write block first (0 = off, for A/B timing)
   float* part;   // split-K over workgroups with a finishing launch: partial tiles [split][M][N] go here, no epilogue
+  int ldsc;      // the A-prologue coefficients are folded from raw BatchNorm sums into an LDS table in the setup phase
+                 // (mmvqa_bn_fold) and the K loop reads them there
+  // persistent ("stream-K") form: the grid is sk_G workgroups, each walks a contiguous run of the launch's K-tile
+  // iterations (tiles x K-tiles per tile, tile-major), so that every workgroup does the same amount of matrix work
+  // whatever the tile count.  A tile whose K range is cut over several workgroups is completed by whichever of them
+  // arrives LAST (a ticket per tile; nobody waits): the others publish their partial tile to sk_part.
+  int sk_G;            // 0: one workgroup per (tile, split) as the grid says
+  int sk_gx, sk_gy;    // tile grid
+  int sk_slots;        // partial tiles a tile can receive (most contributors of one tile)
+  float* sk_part;      // [tile][sk_slots][BM*BN]
+  unsigned* sk_cnt;    // [tile] arrival tickets, zero before and after every launch
   int xcd;       // workgroup ids are dealt round-robin to the 8 XCDs: renumber so that an XCD gets a CONTIGUOUS run of
                  // tiles (1: the N-tiles of an M-panel, 2: the M-tiles of an N-panel share that XCD's L2 instead of
                  // pulling the panel into up to 8 of them)
@@ -61,6 +72,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 #define MAX_TAPS 32
+#define SC1_AUX 16       // cache-policy bits of the raw buffer builtins on gfx950: 1 = sc0, 2 = nt, 16 = sc1 (write-through / L1 bypass)
+#define SK_PART_MAX 6    // most contributors of one tile in the persistent form (host-checked)
+#define TRY_RET(x) do { int r_ = (x); if (r_ != MMVQA_OK) return r_; } while (0)
 
 // Phase timestamps of every workgroup (tools/igemm_trace.py builds the library with -DIGEMM_TRACE):
 // [wg][8] = {entry, loader state ready, first tile in LDS, K loop done, end} in s_memtime ticks (per-XCD counter),
@@ -117,7 +131,7 @@ extern "C" int mmvqa_debug_set_trace(unsigned long long* buf) {
 // the sum of the partial tiles in the split-K finishing kernel.  smem: BN*3 doubles + BN floats for the reductions
 // (free to overwrite once every thread has read its rows).
 template <int BM, int BN, int NT, class Src>
-__device__ __forceinline__ void general_epilogue(const GemmParams& p, int m0, int n0, int tid, float* smem, Src src) {
+__device__ __forceinline__ void general_epilogue(const GemmParams& p, int m0, int n0, int tid, float* smem, int slot_seed, Src src) {
   constexpr int CH = BN / 4;            // float4 chunks per tile row
   constexpr int RP = NT / CH;           // rows per pass of the whole workgroup
   constexpr int NPASS = BM / RP;
@@ -267,7 +281,7 @@ __device__ __forceinline__ void general_epilogue(const GemmParams& p, int m0, in
       if (tid < BN && n0 + tid < N) {
         if (st1) {
           const double* d = red + tid * 3;
-          const int slot = (blockIdx.y + blockIdx.x * 7 + blockIdx.z * 3) & (MMVQA_STAT_SLOTS - 1);
+          const int slot = slot_seed & ((p.stat_slots > 0 ? p.stat_slots : MMVQA_STAT_SLOTS) - 1);
           double* d1 = st1 + ((size_t)slot * N + n0 + tid) * 2;
           atomicAdd(d1, d[0]);
           atomicAdd(d1 + 1, d[1]);
@@ -286,7 +300,10 @@ __device__ __forceinline__ void general_epilogue(const GemmParams& p, int m0, in
 // KS = intra-workgroup split of every K-tile over KS groups of 4 waves (KS*256 threads): for problems
 // with fewer workgroups than CUs it doubles the waves per SIMD (latency hiding) at the price of one
 // LDS reduction at the end.
-template <int BM, int BN, int BK, int KIND, bool NCHW, int KS>
+// PERSIST: the persistent ("stream-K") form is its own instantiation -- the segment loop around the body invites the
+// compiler to hoist everything loop-invariant out of it and keep it in registers for the whole kernel (measured: 156 ->
+// 256 VGPRs with spills for the 64x64x32 forward tile); the one-workgroup-per-tile form must not pay for that.
+template <int BM, int BN, int BK, int KIND, bool NCHW, int KS, bool PERSIST = false>
 __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, const GemmAux x) {
   constexpr int NT = 256 * KS;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -312,13 +329,40 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
   float* As = smem;                 // [2][A_TILE]
   float* Bs = smem + 2 * A_TILE;    // [2][B_TILE]
   int* taptab = reinterpret_cast<int*>(smem + 2 * A_TILE + 2 * B_TILE);  // [MAX_TAPS]
+  float* ctab = smem + 2 * A_TILE + 2 * B_TILE + MAX_TAPS;               // [3][channels]: folded BatchNorm coefficients
 
-  const int tid = threadIdx.x;
+  // ------------------------------------------------------------------ work of this workgroup
+  constexpr bool persistent = PERSIST;
+  const int nkt_total = (p.K + BK - 1) / BK;
+  __shared__ int sk_last;
+  long long sk_it = 0, sk_end = 0;   // persistent: this workgroup's run of K-tile iterations [sk_it, sk_end)
+  unsigned sk_Lg = 0;
+  const unsigned long long sk_T = (unsigned long long)x.sk_gx * x.sk_gy * nkt_total;
+  if (persistent) {
+    // hardware id L runs on XCD L % 8: give every XCD a contiguous run of logical ids (neighbouring tiles share operands)
+    const unsigned L = blockIdx.x, G = (unsigned)x.sk_G, per = G >> 3;
+    sk_Lg = (x.xcd && L < 8u * per) ? (L & 7u) * per + (L >> 3) : L;
+    sk_it = (long long)((unsigned long long)sk_Lg * sk_T / G);
+    sk_end = (long long)((unsigned long long)(sk_Lg + 1) * sk_T / G);
+  }
+  for (bool sk_first = true;; sk_first = false) {
+  int tid = threadIdx.x;
+  if constexpr (persistent) asm volatile("" : "+v"(tid));   // per-thread state is rebuilt per segment, not hoisted and kept
   const int lane = tid & 63, wave = (tid >> 6) & 3, ks = tid >> 8;
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (x.xcd) {
+  int sk_tile = 0, sk_k0 = 0, sk_k1 = nkt_total;
+  if (persistent) {
+    if (sk_it >= sk_end) break;
+    sk_tile = (int)(sk_it / nkt_total);
+    sk_k0 = (int)(sk_it - (long long)sk_tile * nkt_total);
+    sk_k1 = (sk_end - sk_it < (long long)(nkt_total - sk_k0)) ? sk_k0 + (int)(sk_end - sk_it) : nkt_total;
+    sk_it += sk_k1 - sk_k0;
+    if (x.xcd == 2) { by = sk_tile % x.sk_gy; bx = sk_tile / x.sk_gy; } else { bx = sk_tile % x.sk_gx; by = sk_tile / x.sk_gx; }
+    bz = 0;
+    if (!sk_first) __syncthreads();   // the previous segment's epilogue is done with the shared memory
+  } else if (x.xcd) {
     // hardware id L goes to XCD L % 8; logical id Lg: XCD j owns the run [j*per, (j+1)*per), the < 8 ids past 8*per keep
     // their number.  xcd == 1: N-tiles of an M-panel are consecutive (they share operand A); 2: M-tiles of an N-panel are
     const unsigned gx = gridDim.x, gy = gridDim.y;
@@ -343,10 +387,9 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
   const int lm0 = m0, ln0 = n0;
 #endif
 
-  // K range of this split
-  const int nkt_total = (p.K + BK - 1) / BK;
-  const int kt_begin = bz * p.ktiles_per_split;
-  int kt_end = kt_begin + p.ktiles_per_split;
+  // K range of this split / segment
+  const int kt_begin = persistent ? sk_k0 : bz * p.ktiles_per_split;
+  int kt_end = persistent ? sk_k1 : kt_begin + p.ktiles_per_split;
   if (kt_end > nkt_total) kt_end = nkt_total;
   const int nkt = kt_end - kt_begin;
   const int k_begin = kt_begin * BK;
@@ -361,6 +404,30 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     int kh = t / p.g_KW, kw = t - kh * p.g_KW;
     int off = (KIND == KIND_FWD) ? (kh * p.g_SW + kw) * p.a_ld : -((kh / s) * p.g_SW + (kw / s)) * p.a_ld;
     taptab[tid] = off;
+  }
+  // ------------------------------------------------------------------ BatchNorm coefficients from raw sums (mmvqa_bn_fold)
+  // FWD / DGRAD: all g_Cs channels of the gathered operand (one channel per thread and pass); WGRAD: the BM channels
+  // (= output rows) of this workgroup.  Workgroup (0,0,0) publishes what the separate coefficient launch would write.
+  const int fold_C = A_ROWK ? p.g_Cs : BM;
+  if (x.ldsc) {
+    const BnFold& f = p.a_fold;
+    const bool pub = f.publish && (persistent ? (sk_Lg == 0 && sk_first) : (bx == 0 && by == 0 && bz == 0));
+    if constexpr (A_ROWK) {
+      for (int c = tid; c < fold_C; c += NT) {
+        float k0, k1, k2 = 0.f;
+        if (f.bwd) bn_fold_bwd(f, fold_C, c, pub, k0, k1, k2); else bn_fold_fwd(f, fold_C, c, pub, k0, k1);
+        ctab[c] = k0; ctab[fold_C + c] = k1;
+        if (f.bwd) ctab[2 * fold_C + c] = k2;
+      }
+      if (pub && tid == 0 && !f.bwd && f.nbt) *f.nbt += f.reps;
+    } else {
+      if (tid < BM) {
+        const int c = lm0 + tid;
+        float k0 = 1.f, k1 = 0.f, k2 = 0.f;
+        if (c < p.M) { if (f.bwd) bn_fold_bwd(f, p.M, c, false, k0, k1, k2); else bn_fold_fwd(f, p.M, c, false, k0, k1); }
+        ctab[tid] = k0; ctab[BM + tid] = k1; ctab[2 * BM + tid] = k2;
+      }
+    }
   }
   __syncthreads();
 
@@ -434,8 +501,14 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
       a_mask[r] = (i < p.M) ? 1u : 0u;
     }
     if (p.a_pro != PRO_NONE && i < p.M) {   // channel = output row index i: loop invariant
-      ac0_i = ld4(p.a_c0 + i); ac1_i = ld4(p.a_c1 + i);
-      if (p.a_pro == PRO_DZ) ac2_i = ld4(p.a_c2 + i);
+      if (x.ldsc) {
+        ac0_i = *reinterpret_cast<const f32x4*>(&ctab[akm_x4 * 4]);
+        ac1_i = *reinterpret_cast<const f32x4*>(&ctab[BM + akm_x4 * 4]);
+        ac2_i = *reinterpret_cast<const f32x4*>(&ctab[2 * BM + akm_x4 * 4]);
+      } else {
+        ac0_i = ld4(p.a_c0 + i); ac1_i = ld4(p.a_c1 + i);
+        if (p.a_pro == PRO_DZ) ac2_i = ld4(p.a_c2 + i);
+      }
     }
   }
 
@@ -514,10 +587,11 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
   // The whole K loop is instantiated per prologue mode so that its body is straight-line code
   // (loads -> MFMAs -> LDS writes in ONE basic block): the compiler can then slot the address
   // arithmetic and the prologue math between the 64-cycle MFMAs instead of running them serially.
-  auto run = [&](auto APRO_T, auto BPRO_T, auto FAST_T) __attribute__((always_inline)) {
+  auto run = [&](auto APRO_T, auto BPRO_T, auto FAST_T, auto LDSC_T) __attribute__((always_inline)) {
     constexpr int APRO = decltype(APRO_T)::value;
     constexpr int BPRO = decltype(BPRO_T)::value;
     constexpr int FAST = decltype(FAST_T)::value;
+    constexpr bool LDSC = decltype(LDSC_T)::value;   // K-loop coefficient reads from the LDS table (uniform-tap loaders only)
     constexpr bool A_TWO = (APRO == PRO_DZ);
     constexpr bool A_AFF = (APRO == PRO_AFFINE_RELU || APRO == PRO_AFFINE_SILU || APRO == PRO_SILU_GATE);
     constexpr bool B_AFF = (BPRO == PRO_AFFINE_RELU || BPRO == PRO_AFFINE_SILU || BPRO == PRO_SILU_GATE);
@@ -736,7 +810,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
           const int off = (a_base[r] + vshift + a_kq) * 4;
           f_voffA[r] = (FAST == 2 || (a_mask[r] & 1u)) ? off : BIG;
         }
-        if constexpr (A_AFF || A_TWO) {
+        if constexpr ((A_AFF || A_TWO) && !LDSC) {
           rC0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_c0, 0, p.g_Cs * 4, FLAGS);
           rC1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_c1, 0, p.g_Cs * 4, FLAGS);
           rC2 = __builtin_amdgcn_make_buffer_rsrc((void*)(APRO == PRO_DZ ? p.a_c2 : p.a_c1), 0, p.g_Cs * 4, FLAGS);
@@ -822,7 +896,11 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
         f_sC = live ? f_c * 4 : BIG;
         if constexpr (KIND == KIND_DGRAD) f_sB = live ? (f_c * p.b_ld + f_tap * p.b_tapstride) * 4 : BIG;
         else f_sB = f_runB;
-        if constexpr (A_AFF || A_TWO) {
+        if constexpr ((A_AFF || A_TWO) && LDSC) {
+          const float* cp = ctab + f_c + a_kq;          // f_c < g_Cs always: in range also for tiles past the end
+          S.ac0 = *reinterpret_cast<const f32x4*>(cp); S.ac1 = *reinterpret_cast<const f32x4*>(cp + fold_C);
+          if constexpr (APRO == PRO_DZ) S.ac2 = *reinterpret_cast<const f32x4*>(cp + 2 * fold_C);
+        } else if constexpr (A_AFF || A_TWO) {
           S.ac0 = bload(rC0, f_voffC, f_sC); S.ac1 = bload(rC1, f_voffC, f_sC);
           if constexpr (APRO == PRO_DZ) S.ac2 = bload(rC2, f_voffC, f_sC);
         }
@@ -1137,57 +1215,64 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     using G = std::integral_constant<int, 0>;    // general loaders
     using F1 = std::integral_constant<int, 1>;   // uniform-tap loaders
     using F2 = std::integral_constant<int, 2>;   // uniform-tap loaders + halo mask
+    using L0 = std::integral_constant<bool, false>;
+    using L1 = std::integral_constant<bool, true>;   // folded coefficients read from LDS (host: only with F1 / F2, or WGRAD)
     if constexpr (NCHW) {
-      if (KIND == KIND_WGRAD && p.a_pro == PRO_DZ) run(I2{}, I0{}, G{}); else run(I0{}, I0{}, G{});
+      if (KIND == KIND_WGRAD && p.a_pro == PRO_DZ) run(I2{}, I0{}, G{}, L0{}); else run(I0{}, I0{}, G{}, L0{});
     } else if constexpr (KIND == KIND_FWD) {
       if (x.fast == 1) {
-        if (p.a_pro == PRO_AFFINE_RELU) run(I1{}, I0{}, F1{}); else run(I0{}, I0{}, F1{});
+        if (p.a_pro == PRO_AFFINE_RELU) { if (x.ldsc) run(I1{}, I0{}, F1{}, L1{}); else run(I1{}, I0{}, F1{}, L0{}); }
+        else run(I0{}, I0{}, F1{}, L0{});
       } else if (x.fast == 2) {
-        if (p.a_pro == PRO_AFFINE_RELU) run(I1{}, I0{}, F2{}); else run(I0{}, I0{}, F2{});
+        if (p.a_pro == PRO_AFFINE_RELU) { if (x.ldsc) run(I1{}, I0{}, F2{}, L1{}); else run(I1{}, I0{}, F2{}, L0{}); }
+        else run(I0{}, I0{}, F2{}, L0{});
       } else {
         switch (p.a_pro) {
-          case PRO_AFFINE_RELU: run(I1{}, I0{}, G{}); break;
-          case PRO_AFFINE_SILU: run(I4{}, I0{}, G{}); break;
-          case PRO_SILU_GATE: run(I5{}, I0{}, G{}); break;
-          default: run(I0{}, I0{}, G{});
+          case PRO_AFFINE_RELU: run(I1{}, I0{}, G{}, L0{}); break;
+          case PRO_AFFINE_SILU: run(I4{}, I0{}, G{}, L0{}); break;
+          case PRO_SILU_GATE: run(I5{}, I0{}, G{}, L0{}); break;
+          default: run(I0{}, I0{}, G{}, L0{});
         }
       }
     } else if constexpr (KIND == KIND_DGRAD) {
       if (x.fast == 1) {
-        if (p.a_pro == PRO_DZ) run(I2{}, I0{}, F1{}); else run(I0{}, I0{}, F1{});
+        if (p.a_pro == PRO_DZ) { if (x.ldsc) run(I2{}, I0{}, F1{}, L1{}); else run(I2{}, I0{}, F1{}, L0{}); }
+        else run(I0{}, I0{}, F1{}, L0{});
       } else if (x.fast == 2) {
-        if (p.a_pro == PRO_DZ) run(I2{}, I0{}, F2{}); else run(I0{}, I0{}, F2{});
+        if (p.a_pro == PRO_DZ) { if (x.ldsc) run(I2{}, I0{}, F2{}, L1{}); else run(I2{}, I0{}, F2{}, L0{}); }
+        else run(I0{}, I0{}, F2{}, L0{});
       } else {
-        if (p.a_pro == PRO_DZ) run(I2{}, I0{}, G{}); else run(I0{}, I0{}, G{});
+        if (p.a_pro == PRO_DZ) run(I2{}, I0{}, G{}, L0{}); else run(I0{}, I0{}, G{}, L0{});
       }
     } else {
+      // weight gradient: the A' coefficients are loop invariant (registers), whatever their source
       if (x.fast == 1) {
         if (p.a_pro == PRO_DZ) {
-          if (p.b_pro == PRO_AFFINE_RELU) run(I2{}, I1{}, F1{}); else run(I2{}, I0{}, F1{});
+          if (p.b_pro == PRO_AFFINE_RELU) run(I2{}, I1{}, F1{}, L0{}); else run(I2{}, I0{}, F1{}, L0{});
         } else {
-          if (p.b_pro == PRO_AFFINE_RELU) run(I0{}, I1{}, F1{}); else run(I0{}, I0{}, F1{});
+          if (p.b_pro == PRO_AFFINE_RELU) run(I0{}, I1{}, F1{}, L0{}); else run(I0{}, I0{}, F1{}, L0{});
         }
       } else if (x.fast == 2) {
         if constexpr (TM * TN == 1) {
           if (p.a_pro == PRO_DZ) {
-            if (p.b_pro == PRO_AFFINE_RELU) run(I2{}, I1{}, F2{}); else run(I2{}, I0{}, F2{});
+            if (p.b_pro == PRO_AFFINE_RELU) run(I2{}, I1{}, F2{}, L0{}); else run(I2{}, I0{}, F2{}, L0{});
           } else {
-            if (p.b_pro == PRO_AFFINE_RELU) run(I0{}, I1{}, F2{}); else run(I0{}, I0{}, F2{});
+            if (p.b_pro == PRO_AFFINE_RELU) run(I0{}, I1{}, F2{}, L0{}); else run(I0{}, I0{}, F2{}, L0{});
           }
         }
       } else if (p.a_pro == PRO_DZ) {
         switch (p.b_pro) {
-          case PRO_AFFINE_RELU: run(I2{}, I1{}, G{}); break;
-          case PRO_AFFINE_SILU: run(I2{}, I4{}, G{}); break;
-          case PRO_SILU_GATE: run(I2{}, I5{}, G{}); break;
-          default: run(I2{}, I0{}, G{});
+          case PRO_AFFINE_RELU: run(I2{}, I1{}, G{}, L0{}); break;
+          case PRO_AFFINE_SILU: run(I2{}, I4{}, G{}, L0{}); break;
+          case PRO_SILU_GATE: run(I2{}, I5{}, G{}, L0{}); break;
+          default: run(I2{}, I0{}, G{}, L0{});
         }
       } else {
         switch (p.b_pro) {
-          case PRO_AFFINE_RELU: run(I0{}, I1{}, G{}); break;
-          case PRO_AFFINE_SILU: run(I0{}, I4{}, G{}); break;
-          case PRO_SILU_GATE: run(I0{}, I5{}, G{}); break;
-          default: run(I0{}, I0{}, G{});
+          case PRO_AFFINE_RELU: run(I0{}, I1{}, G{}, L0{}); break;
+          case PRO_AFFINE_SILU: run(I0{}, I4{}, G{}, L0{}); break;
+          case PRO_SILU_GATE: run(I0{}, I5{}, G{}, L0{}); break;
+          default: run(I0{}, I0{}, G{}, L0{});
         }
       }
     }
@@ -1248,6 +1333,51 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     }
   };
 
+  if (persistent && !p.c_atomic && (sk_k0 != 0 || sk_k1 != nkt_total)) {
+    // This segment covers only a part of its tile's K range.  Every contributor publishes its partial tile (write-through
+    // stores, MI355X_MICROARCH "Valid forms": all stores of the handed-off bytes sc1, every storing wave drains them, a
+    // workgroup barrier, then ONE lane's agent-scope atomic) and draws a ticket; the contributor whose ticket is the
+    // last adds the other partial tiles (sc1 loads) to its own and runs the epilogue.  Nobody waits for anybody.
+    const unsigned long long G = (unsigned long long)x.sk_G;
+    const unsigned long long i0 = (unsigned long long)sk_tile * nkt_total, i1 = i0 + nkt_total - 1;
+    const int w_first = (int)(((i0 + 1) * G - 1) / sk_T), w_last = (int)(((i1 + 1) * G - 1) / sk_T);
+    const int n_contrib = w_last - w_first + 1, my = (int)sk_Lg - w_first;
+    constexpr int Q = BM * BN / 4;   // float4 of a tile
+    __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(x.sk_part + (size_t)sk_tile * x.sk_slots * (BM * BN)), 0,
+                                                                  x.sk_slots * BM * BN * 4, 0x00020000);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    for (int i = tid; i < Q; i += NT) {
+      const int r = i / (BN / 4), c = i - r * (BN / 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[r * LDC + c * 4]);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rP, (my * Q + i) * 16, 0, SC1_AUX);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's partial stores have left
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = atomicAdd(&x.sk_cnt[sk_tile], 1u);
+      const int last = old == (unsigned)(n_contrib - 1);
+      if (last) atomicExch(&x.sk_cnt[sk_tile], 0u);   // tickets are zero again for the next launch
+      sk_last = last;
+    }
+    __syncthreads();
+    if (!sk_last) continue;
+    for (int i = tid; i < Q; i += NT) {
+      const int r = i / (BN / 4), c = i - r * (BN / 4);
+      f32x4 t[SK_PART_MAX];
+#pragma unroll
+      for (int q = 0; q < SK_PART_MAX; ++q) {
+        t[q] = f32x4{0, 0, 0, 0};
+        if (q < n_contrib && q != my)
+          t[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rP, (q * Q + i) * 16, 0, SC1_AUX));
+      }
+      f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[r * LDC + c * 4]);
+#pragma unroll
+      for (int q = 0; q < SK_PART_MAX; ++q) v += t[q];
+      *reinterpret_cast<f32x4*>(&ctile[r * LDC + c * 4]) = v;
+    }
+    __syncthreads();
+  }
+
   if (x.part) {
     // split-K over workgroups, finished by splitk_finish_kernel: this workgroup's partial tile, row-wise 16-byte stores
     float* P = x.part + (size_t)bz * M * N;
@@ -1258,7 +1388,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
       stv(P, (size_t)row * N + col, *reinterpret_cast<const f32x4*>(&ctile[rl * LDC + c4 * 4]));
     }
     TRACE_MARK(4);
-    return;
+    return;   // (never with the persistent form: host-checked)
   }
 
   if (p.c_atomic) {
@@ -1272,6 +1402,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
       if (row < M && cc < N) atomicAdd(&C[(size_t)row * ldc + cc], ctile[rl * LDC + cl]);
     }
     TRACE_MARK(4);
+    if (persistent) continue;   // partial or whole, a segment of an accumulating product just adds its tile
     return;
   }
 
@@ -1341,13 +1472,16 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     return;
   }
 
-  general_epilogue<BM, BN, NT>(p, m0, n0, tid, smem,
+  general_epilogue<BM, BN, NT>(p, m0, n0, tid, smem, persistent ? by + bx * 7 : (int)(blockIdx.y + blockIdx.x * 7 + blockIdx.z * 3),
                                [&](int rl, int cq) __attribute__((always_inline)) {
                                  return *reinterpret_cast<const f32x4*>(&ctile[rl * LDC + cq * 4]);
                                });
   TRACE_MARK(4);
+  if (!persistent) break;
+  }   // next segment
 }
 
+constexpr int FOLD_MAX_FLOATS = 3072;   // largest LDS table of folded BatchNorm coefficients (12 KB: 1024 channels x P, Q, R)
 constexpr int SK_MAX = 8;   // most workgroups one output tile's K range is split over (finishing-launch form)
 
 // Second launch of a split-K FWD / DGRAD product: sums the partial tiles [nsplit][M][N] and runs the general epilogue
@@ -1359,7 +1493,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmParams p, 
   const int tid = threadIdx.x, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int M = p.M, N = p.N;
   const size_t MN = (size_t)M * N;
-  general_epilogue<BM, BN, 256>(p, m0, n0, tid, reinterpret_cast<float*>(smem_d),
+  general_epilogue<BM, BN, 256>(p, m0, n0, tid, reinterpret_cast<float*>(smem_d), (int)(blockIdx.y + blockIdx.x * 7),
                                 [&](int rl, int cq) __attribute__((always_inline)) {
                                   f32x4 v = {0, 0, 0, 0};
                                   const int row = m0 + rl, col = n0 + cq * 4;
@@ -1401,19 +1535,22 @@ static FastDiv make_fastdiv(int d) {
 }
 
 template <int BM, int BN, int BK, int KIND, bool NCHW, int KS = 1>
-static int launch_cfg(const GemmParams& p, hipStream_t stream) {
+static int launch_cfg(GemmParams p, hipStream_t stream) {
   constexpr bool A_ROWK = (KIND != KIND_WGRAD);
   constexpr bool B_ROWK = (KIND == KIND_FWD);
   constexpr int A_TILE = A_ROWK ? BM * (BK + 4) : BK * (BM + 4);
   constexpr int B_TILE = B_ROWK ? BN * (BK + 4) : BK * (BN + 4);
   constexpr size_t tile_floats = (size_t)(2 * A_TILE + 2 * B_TILE + MAX_TAPS);
   constexpr size_t epi_floats = (size_t)BM * (BN + 4) + 8 * BN;   // staged output tile + tap accumulators
-  constexpr size_t smem = (tile_floats > epi_floats ? tile_floats : epi_floats) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  constexpr size_t smem_max = (tile_floats + FOLD_MAX_FLOATS > epi_floats ? tile_floats + FOLD_MAX_FLOATS : epi_floats) * sizeof(float);
+  // (per device: a second device in the process needs the attribute too; the call is cheap)
+  static int attr_dev_mask = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(attr_dev_mask >> (dev & 31) & 1)) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, KIND, NCHW, KS>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
+    attr_dev_mask |= 1 << (dev & 31);
   }
   GemmAux x;
   x.ohw = make_fastdiv(p.g_OH * p.g_OW);
@@ -1448,21 +1585,77 @@ static int launch_cfg(const GemmParams& p, hipStream_t stream) {
         x.fast = 2;
     }
   }
+  // BatchNorm coefficients of the A prologue folded in the kernel's setup (mmvqa_bn_fold).  The K loop reads the LDS table
+  // only in its uniform-tap forms; the weight gradient keeps its (loop-invariant) coefficients in registers.  Anything
+  // else -- general loaders, a table beyond FOLD_MAX_FLOATS -- gets the coefficient launch in front, as before.
+  x.ldsc = 0;
+  size_t fold_floats = 0;
+  if (p.a_fold.stat) {
+    const int ncoef = p.a_fold.bwd ? 3 : 2;
+    const size_t need = A_ROWK ? (size_t)ncoef * p.g_Cs : (size_t)3 * BM;
+    const bool pro_ok = p.a_fold.bwd ? p.a_pro == PRO_DZ : p.a_pro == PRO_AFFINE_RELU;
+    if (pro_ok && need <= FOLD_MAX_FLOATS && (KIND == KIND_WGRAD || x.fast != 0)) {
+      x.ldsc = 1;
+      fold_floats = need;
+    } else {
+      const BnFold f = p.a_fold;
+      const int C = A_ROWK ? p.g_Cs : p.M;
+      if (!f.publish || !f.out0 || !f.out1 || !f.out2)
+        return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: this launch cannot fold its BatchNorm coefficients in the kernel and has nowhere to publish them");
+      if (f.bwd)
+        TRY_RET(k_bn_coef_bwd(stream, f.stat, C, f.count, f.gamma, f.mean, f.invstd, 1, f.out0, f.out1, f.out2, f.dgamma, f.dbeta));
+      else
+        TRY_RET(k_bn_coef_fwd_keep(stream, f.stat, C, f.count, f.eps, f.gamma, f.beta, f.run_mean, f.run_var, f.nbt, f.keep,
+                                   f.reps, 1, f.out0, f.out1, f.out2, f.out3));
+      p.a_c0 = f.out0; p.a_c1 = f.out1; p.a_c2 = f.out2;
+      p.a_fold.stat = nullptr;
+    }
+  }
+  const size_t smem = ((tile_floats + fold_floats > epi_floats ? tile_floats + fold_floats : epi_floats)) * sizeof(float);
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splitk);
+  // persistent ("stream-K") form
+  x.sk_G = 0; x.sk_gx = (int)grid.x; x.sk_gy = (int)grid.y; x.sk_slots = 0; x.sk_part = nullptr; x.sk_cnt = nullptr;
+  if (p.persist > 0 && !NCHW && BM == 64 && BN == 64 && p.epi_mode == EPI_PLAIN && !x.part && p.splitk == 1) {
+    const long long tiles = (long long)grid.x * grid.y, nkt = (p.K + BK - 1) / BK, T = tiles * nkt;
+    long long G = p.persist < T ? p.persist : T;
+    bool ok = G >= 8;
+    if (ok && !p.c_atomic) {
+      const long long per = T / G;                          // K-tile iterations per workgroup (at least)
+      const long long slots = (nkt + per - 1) / per + 1;    // a tile's K range meets at most this many runs
+      ok = slots <= SK_PART_MAX && p.sk_ws && p.sk_cnt && tiles <= p.sk_cnt_n &&
+           tiles * slots * (long long)(BM * BN) <= p.sk_ws_floats;
+      x.sk_slots = (int)slots; x.sk_part = p.sk_ws; x.sk_cnt = p.sk_cnt;
+    }
+    if (ok) { x.sk_G = (int)G; grid = dim3((unsigned)G, 1, 1); }
+  }
   static const int xcd_on = getenv("MMVQA_IGEMM_NOXCD") ? 0 : 1;   // A/B switch
   const long nwg = (long)grid.x * grid.y * grid.z;
   x.xcd = 0;
-  if (xcd_on && nwg >= 32 && !NCHW) {
+  if (xcd_on && (nwg >= 32 || x.sk_G) && !NCHW) {
     // bytes behind the row panels (A side) and the column panels (B side): keep the larger one XCD-local
     double a_bytes, b_bytes;
     if (KIND == KIND_WGRAD) { a_bytes = (double)p.K * p.M * (p.a_pro == PRO_DZ ? 2 : 1); b_bytes = (double)p.K * p.g_Cs; }
     else if (KIND == KIND_FWD) { a_bytes = (double)p.M * p.g_stride * p.g_stride * p.g_Cs; b_bytes = (double)p.N * p.K; }
     else { a_bytes = (double)p.M * p.g_Cs * (p.a_pro == PRO_DZ ? 2 : 1); b_bytes = (double)p.N * p.K; }
-    x.xcd = (b_bytes > a_bytes && grid.y > 1) ? 2 : (grid.x > 1 ? 1 : 0);
+    x.xcd = (b_bytes > a_bytes && x.sk_gy > 1) ? 2 : (x.sk_gx > 1 ? 1 : 0);
+    if (x.sk_G && !x.xcd) x.xcd = 1;
   }
   if (getenv("MMVQA_IGEMM_LOG"))   // one line per launch: which loader family a shape gets (diagnostics)
-    fprintf(stderr, "igemm kind %d fast %d tile %dx%dx%d ks %d M %d N %d K %d Cs %d taps %d stride %d apro %d bpro %d splitk %d\n", KIND, x.fast,
-            BM, BN, BK, KS, p.M, p.N, p.K, p.g_Cs, p.g_KH * p.g_KW, p.g_stride, p.a_pro, p.b_pro, p.splitk);
+    fprintf(stderr, "igemm kind %d fast %d tile %dx%dx%d ks %d M %d N %d K %d Cs %d taps %d stride %d apro %d bpro %d splitk %d persist %d fold %d\n", KIND, x.fast,
+            BM, BN, BK, KS, p.M, p.N, p.K, p.g_Cs, p.g_KH * p.g_KW, p.g_stride, p.a_pro, p.b_pro, p.splitk, x.sk_G, x.ldsc);
+  if constexpr (BM == 64 && BN == 64 && !NCHW) {
+    if (x.sk_G) {
+      static int attr_dev_mask_p = 0;
+      if (!(attr_dev_mask_p >> (dev & 31) & 1)) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK, KIND, NCHW, KS, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
+        attr_dev_mask_p |= 1 << (dev & 31);
+      }
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, KIND, NCHW, KS, true>), grid, dim3(256 * KS), smem, stream, p, x);
+      KERNEL_CHECK_RET();
+      return MMVQA_OK;
+    }
+  }
   hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, KIND, NCHW, KS>), grid, dim3(256 * KS), smem, stream, p, x);
   KERNEL_CHECK_RET();
   if (x.part) {
@@ -1495,7 +1688,7 @@ static std::string tune_key(const GemmParams& p, int kind, int nchw) {
   snprintf(buf, sizeof(buf), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", kind, nchw, p.M, p.N, p.K,
            p.g_KH * p.g_KW, p.g_stride, p.g_Cs, p.a_pro, p.b_pro, p.epi_mode, p.act | (p.dact << 4),
            (p.stat1 ? 1 : 0) | (p.stat2 ? 2 : 0) | (p.Mk ? 4 : 0) | (p.R ? 8 : 0) | (p.Cpre ? 16 : 0) |
-               (p.colsum ? 32 : 0) | (p.bias ? 64 : 0) | (p.sk_ws ? 128 : 0),
+               (p.colsum ? 32 : 0) | (p.bias ? 64 : 0) | (p.sk_ws ? 128 : 0) | (p.a_fold.stat ? 256 : 0) | (p.sk_cnt ? 512 : 0),
            p.c_atomic, p.splitk);
   return buf;
 }
@@ -1528,8 +1721,16 @@ static int validate_desc(const GemmParams& p, int kind, int nchw) {
     if (kind == KIND_DGRAD && ((long)p.b_ld < (taps - 1) * p.b_tapstride + p.N)) BAD("dgrad: b_ld=%d < (taps-1)*tapstride+N", p.b_ld);
     if (p.epi_mode == EPI_PLAIN && p.c_ld < p.N) BAD("c_ld=%d < N=%d", p.c_ld, p.N);
   }
-  if (p.a_pro != PRO_NONE && (!p.a_c0 || !p.a_c1)) BAD("A prologue %d without coefficients", p.a_pro);
-  if (p.a_pro == PRO_DZ && (!p.A2 || !p.a_c2)) BAD("BatchNorm-backward prologue without A2 / c2");
+  if (p.a_fold.stat) {
+    const mmvqa_bn_fold& f = p.a_fold;
+    if (f.slots <= 0 || f.slots > MMVQA_STAT_SLOTS || (f.slots & (f.slots - 1))) BAD("a_fold.slots=%d is not a power of two <= %d", f.slots, MMVQA_STAT_SLOTS);
+    if (!(f.count > 0.0) || !f.gamma) BAD("a_fold without count / gamma");
+    if (f.bwd ? (p.a_pro != PRO_DZ || !f.mean || !f.invstd) : (p.a_pro != PRO_AFFINE_RELU || !f.beta)) BAD("a_fold.bwd=%d does not match A prologue %d (or mean / invstd / beta missing)", f.bwd, p.a_pro);
+    if (f.publish && (!f.out0 || !f.out1 || !f.out2 || (f.bwd ? (!f.dgamma || !f.dbeta) : !f.out3))) BAD("a_fold.publish without output arrays");
+    if (nchw && kind != KIND_WGRAD) BAD("a_fold: not for the NCHW stem forward");
+  } else if (p.a_pro != PRO_NONE && (!p.a_c0 || !p.a_c1)) BAD("A prologue %d without coefficients", p.a_pro);
+  if (p.a_pro == PRO_DZ && (!p.A2 || (!p.a_c2 && !p.a_fold.stat))) BAD("BatchNorm-backward prologue without A2 / c2");
+  if (p.stat_slots < 0 || p.stat_slots > MMVQA_STAT_SLOTS || (p.stat_slots & (p.stat_slots - 1))) BAD("stat_slots=%d is not a power of two <= %d", p.stat_slots, MMVQA_STAT_SLOTS);
   if (p.b_pro != PRO_NONE && (!p.b_c0 || !p.b_c1)) BAD("B prologue %d without coefficients", p.b_pro);
   if ((p.a_pro == PRO_SILU_GATE || p.b_pro == PRO_SILU_GATE) && (!p.gate || p.gate_hw <= 0)) BAD("gate prologue without gate tensor");
   if (p.dact != ACT_NONE && !p.Pre) BAD("act' epilogue without the saved pre-activation");
@@ -1552,20 +1753,26 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
   auto it = g_tuner->table.find(key);
   if (it == g_tuner->table.end()) {
     if (!g_tuner->tuning) return launch_one(p, kind, nchw, 0, stream);
-    struct Cand { int tile, splitk; };
+    struct Cand { int tile, splitk, persist; };
     std::vector<Cand> cands;
     const int tiles_f[] = {1, 2, 3, 4, 5, 6}, tiles_w[] = {1, 2, 3, 4, 5, 6};
+    static const bool persist_off = getenv("MMVQA_NO_PERSIST") != nullptr;   // A/B switch: no persistent candidates
     if (kind == KIND_WGRAD && p.splitk <= 0) {
-      for (int t : tiles_w) for (int sk : {0, 1, 2, 3, 4, 6, 8, 12, 16}) cands.push_back({t, sk});
+      for (int t : tiles_w) for (int sk : {0, 1, 2, 3, 4, 6, 8, 12, 16}) cands.push_back({t, sk, 0});
+      // persistent form: an equal share of the K-tile iterations per workgroup, tiles accumulated with atomics as in any split
+      if (!persist_off && p.c_atomic && p.epi_mode == EPI_PLAIN)
+        for (int t : {3, 5, 6}) for (int g : {256, 512, 1024}) cands.push_back({t, 1, g});
     } else if (kind == KIND_WGRAD) {
-      for (int t : tiles_w) cands.push_back({t, p.splitk});
+      for (int t : tiles_w) cands.push_back({t, p.splitk, 0});
     } else if (sk_eligible(p, kind) && p.splitk <= 0 && (long)cdiv(p.M, 64) * cdiv(p.N, 64) <= 224) {
       // few output tiles: also try K split over workgroups with a finishing launch (needs the caller's scratch)
-      for (int t : {3, 5, 6}) for (int sk : {1, 2, 3, 4, 6, 8}) cands.push_back({t, sk});
-      for (int t : {1, 2, 4}) cands.push_back({t, 1});
+      for (int t : {3, 5, 6}) for (int sk : {1, 2, 3, 4, 6, 8}) cands.push_back({t, sk, 0});
+      for (int t : {1, 2, 4}) cands.push_back({t, 1, 0});
     } else {
-      for (int t : tiles_f) cands.push_back({t, p.splitk});
+      for (int t : tiles_f) cands.push_back({t, p.splitk, 0});
     }
+    if (!persist_off && kind != KIND_WGRAD && sk_eligible(p, kind) && p.sk_cnt && p.splitk <= 0)
+      for (int t : {3, 5, 6}) for (int g : {256, 512}) cands.push_back({t, 1, g});
     hipEvent_t e0, e1;
     HIP_CHECK_RET(hipEventCreate(&e0));
     HIP_CHECK_RET(hipEventCreate(&e1));
@@ -1575,6 +1782,7 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     for (const Cand& c : cands) {
       GemmParams q = p;
       q.splitk = c.splitk;
+      q.persist = c.persist;
       int r = launch_one(q, kind, nchw, c.tile, stream);  // warm-up (also sets the LDS attribute)
       if (r != MMVQA_OK) continue;
       HIP_CHECK_RET(hipEventRecord(e0, stream));
@@ -1591,10 +1799,11 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     if (sk_partial && bc.splitk > 1 && best_single < 1e29f && best > 0.85f * best_single) { bc = bc_single; best = best_single; }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
-    it = g_tuner->table.emplace(key, std::make_pair(bc.tile, bc.splitk)).first;
+    it = g_tuner->table.emplace(key, IgemmChoice{bc.tile, bc.splitk, bc.persist}).first;
   }
-  p.splitk = it->second.second;
-  return launch_one(p, kind, nchw, it->second.first, stream);
+  p.splitk = it->second.splitk;
+  p.persist = it->second.persist;
+  return launch_one(p, kind, nchw, it->second.tile, stream);
 }
 
 // tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 (BK 64), 4 = 64x128, 5 = 64x64 with 8 waves (K-tile split in 2),
@@ -1622,6 +1831,10 @@ static int launch_one(GemmParams p, int kind, int nchw, int tile, hipStream_t st
   const int bn = (tile == 1 || tile == 4) ? 128 : 64;
   const int bk = ((tile == 3 || tile == 5) && !nchw) ? 64 : 32;
   const int nkt = cdiv(p.K, bk);
+  if (p.persist > 0) {
+    // persistent form: the workgroups share the K-tile iterations themselves, no split of the grid
+    if (nchw || p.epi_mode != EPI_PLAIN) p.persist = 0; else p.splitk = 1;
+  }
   if (p.splitk <= 0) {
     p.splitk = 1;
     if (kind == KIND_WGRAD) {

@@ -7,9 +7,10 @@
 #include <utility>
 
 // per-shape (tile, split-K) choices of the implicit-GEMM launcher; see igemm.hip
+struct IgemmChoice { int tile, splitk, persist; };   // persist: workgroups of the persistent ("stream-K") form, 0 = off
 struct IgemmTuner {
   bool tuning = false;
-  std::unordered_map<std::string, std::pair<int, int>> table;
+  std::unordered_map<std::string, IgemmChoice> table;
 };
 void mmvqa_set_tuner(IgemmTuner* t);
 int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t stream);
@@ -18,10 +19,17 @@ int mmvqa_launch_attention(const AttnParams& p, int head_dim, int bwd, hipStream
 int k_bn_coef_fwd(hipStream_t st, const double* stat, int C, double count, float eps, const float* gamma,
                   const float* beta, float* run_mean, float* run_var, long long* nbt, float momentum, int reps,
                   int training, float* scale, float* shift, float* mean, float* invstd);
+// same with (1 - momentum)^reps given directly (mmvqa_bn_fold carries it that way)
+int k_bn_coef_fwd_keep(hipStream_t st, const double* stat, int C, double count, float eps, const float* gamma,
+                       const float* beta, float* run_mean, float* run_var, long long* nbt, double keep, int reps,
+                       int training, float* scale, float* shift, float* mean, float* invstd);
 int k_bn_coef_bwd(hipStream_t st, const double* stat, int C, double count, const float* gamma, const float* mean,
                   const float* invstd, int training, float* P, float* Q, float* R, float* dgamma, float* dbeta);
 int k_bn_add_relu(hipStream_t st, const float* z, const float* s, const float* b, const float* idn,
                   const float* ids, const float* idb, float* out, long rows, int C);
+// relu(bn3(z) + [bnd](idn)) with the BatchNorm coefficients folded from raw sums inside the kernel (fd == NULL: plain identity)
+int k_bn_add_relu_fold(hipStream_t st, const float* z, const mmvqa_bn_fold* f3, const float* idn, const mmvqa_bn_fold* fd,
+                       float* out, long rows, int C);
 int k_maxpool_fwd(hipStream_t st, const float* z, const float* s, const float* b, float* out, unsigned char* idx,
                   int N, int H, int W, int C, int OH, int OW);
 int k_maxpool_bwd(hipStream_t st, const float* gp, const unsigned char* idx, const float* extra, const float* z,

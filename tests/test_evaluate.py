@@ -80,8 +80,8 @@ def load_eval_fixture(golden_dir):
 def eval_fixture_oracle_model(g, C):
     from oracle import mmbert_oracle as O
     args = O.make_args(transformer_model="realformer", dataset="VQA-Med", hidden_size=768, n_layers=2, heads=12,
-                       hidden_dropout_prob=0.0, vocab_size=C, resnet_layers=(1, 1, 1, 1), resnet_width=64, bert_max_pos=32,
-                       use_relu=False, cnn_encoder="resnet152")
+                       hidden_dropout_prob=0.0, vocab_size=C, emb_vocab=C, resnet_layers=(1, 1, 1, 1), resnet_width=64,
+                       bert_max_pos=32, use_relu=False, cnn_encoder="resnet152")
     torch.manual_seed(int(g["seed"]))
     orc = O.OracleModel(args)
     LO.perturb_bn_buffers(orc, seed=int(g["bn_seed"]))

@@ -460,6 +460,244 @@ def test_bn_coef_and_add_relu():
     assert int(nbt) == 6
 
 
+PERSIST = [  # (N, H, W, Cin, Cout, K, stride, pad), tile, workgroups
+    ((2, 14, 14, 128, 192, 3, 1, 1), 3, 16), ((2, 14, 14, 128, 192, 3, 1, 1), 5, 29), ((2, 14, 14, 128, 192, 3, 1, 1), 6, 64),
+    ((3, 9, 9, 256, 72, 1, 1, 0), 5, 11), ((2, 12, 12, 64, 128, 3, 2, 1), 6, 37), ((2, 10, 10, 128, 64, 1, 1, 0), 3, 8),
+    ((1, 7, 7, 192, 200, 3, 1, 1), 5, 256),
+]
+
+
+@pytest.mark.parametrize("cfg,tile,G", PERSIST)
+def test_conv_persistent_form(cfg, tile, G):
+    """mmvqa_gemm_desc.persist: G workgroups walk equal shares of the launch's K-tile iterations; tiles whose K range is
+    cut over several workgroups are completed by the last arriver (tickets + partial tiles in sk_ws), accumulating
+    products just add.  Grids that do not divide (G = 29, 37, 11 ...), more workgroups than tiles, the fused BatchNorm
+    prologues / statistics epilogues and the folded coefficients all go through it; results against torch and against
+    the one-workgroup-per-tile launch; the tickets must read zero afterwards (the next launch relies on it)."""
+    N, H, W, Cin, Cout, K, s, p = cfg
+    torch.manual_seed(21)
+    x_raw = torch.randn(N, Cin, H, W)
+    sc, sh = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.3
+    w = torch.randn(Cout, Cin, K, K) / math.sqrt(Cin * K * K)
+    a = torch.relu(x_raw * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    z_ref = F.conv2d(a, wr, stride=s, padding=p)
+    OH, OW = z_ref.shape[2:]
+    xd, wd, scd, shd = nhwc(x_raw), w_ohwi(w), sc.to(dev()), sh.to(dev())
+    ws = torch.zeros(8 << 20, device=dev())
+    cnt = torch.zeros(4096, dtype=torch.int32, device=dev())
+
+    def fwd(persist):
+        z = torch.zeros(N * OH * OW, Cout, device=dev())
+        stat = torch.zeros(L.STAT_SLOTS, Cout, 2, dtype=torch.float64, device=dev())
+        d, _, _ = conv_desc_fwd(xd, wd, N, H, W, Cin, Cout, K, s, p, z)
+        d.a_pro, d.a_c0, d.a_c1 = L.PRO_AFFINE_RELU, P(scd), P(shd)
+        d.stat1, d.stat_bwd, d.stat_slots = P(stat), 0, 4
+        d.sk_ws, d.sk_ws_floats, d.sk_cnt, d.sk_cnt_n, d.persist, d.splitk = P(ws), ws.numel(), P(cnt), cnt.numel(), persist, 1
+        run_igemm(d, L.KIND_FWD, tile=tile)
+        assert float(stat[4:].abs().sum()) == 0.0 and float(stat[:4].abs().sum()) > 0.0   # stat_slots = 4: replicas 0..3 only
+        return z, stat.sum(0).cpu()
+
+    z0, st0 = fwd(0)
+    z1, st1 = fwd(G)
+    assert int(cnt.abs().sum()) == 0, "tickets not back to zero"
+    assert_close(from_nhwc(z1, N, OH, OW, Cout), z_ref, TOL, "persistent forward vs torch")
+    assert_close(z1, z0, 2e-6, "persistent vs one workgroup per tile")
+    assert_close(st1[:, 0], st0[:, 0], 1e-6, "sum")
+    assert_close(st1[:, 1], (z_ref.double() ** 2).sum(dim=(0, 2, 3)), 1e-5, "sumsq")
+    # data gradient with the BatchNorm-backward prologue, ReLU mask and backward statistics
+    Gr = torch.randn_like(z_ref)
+    Pc, Qc, Rc = torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.1, torch.randn(Cout) * 0.1
+    dz = Gr * Pc[None, :, None, None] + z_ref.detach() * Qc[None, :, None, None] + Rc[None, :, None, None]
+    z_ref.backward(dz)
+    Gd, coef = nhwc(Gr), [t.to(dev()) for t in (Pc, Qc, Rc)]
+    mu, istd = (torch.randn(Cin) * 0.1).to(dev()), (torch.rand(Cin) + 0.5).to(dev())
+
+    def dgrad(persist):
+        dx = torch.zeros(N * H * W, Cin, device=dev())
+        bst = torch.zeros(L.STAT_SLOTS, Cin, 2, dtype=torch.float64, device=dev())
+        d = conv_desc_dgrad(Gd, wd, N, H, W, Cin, Cout, K, s, p, dx)
+        d.A2, d.a_pro, d.a_c0, d.a_c1, d.a_c2 = P(z0), L.PRO_DZ, P(coef[0]), P(coef[1]), P(coef[2])
+        d.Mk, d.mk_ld, d.mk_s, d.mk_b = P(xd), Cin, P(scd), P(shd)
+        d.stat1, d.stat_bwd, d.Z1, d.z1_ld, d.mean1, d.invstd1 = P(bst), 1, P(xd), Cin, P(mu), P(istd)
+        d.sk_ws, d.sk_ws_floats, d.sk_cnt, d.sk_cnt_n, d.persist, d.splitk = P(ws), ws.numel(), P(cnt), cnt.numel(), persist, 1
+        run_igemm(d, L.KIND_DGRAD, tile=tile)
+        return dx, bst.sum(0).cpu()
+
+    dx0, b0 = dgrad(0)
+    dx1, b1 = dgrad(G)
+    assert int(cnt.abs().sum()) == 0
+    mask = (x_raw * sc[None, :, None, None] + sh[None, :, None, None] > 0).float()
+    assert_close(from_nhwc(dx1, N, H, W, Cin), a.grad * mask, TOL, "persistent dgrad vs torch")
+    assert_close(dx1, dx0, 2e-6, "persistent dgrad vs one workgroup per tile")
+    assert_close(b1, b0, 1e-6, "backward statistics")
+
+    def wgrad(persist):
+        dw = torch.zeros(Cout, K * K * Cin, device=dev())
+        d = conv_desc_wgrad(Gd, xd, N, H, W, Cin, Cout, K, s, p, dw)
+        d.A2, d.a_pro, d.a_c0, d.a_c1, d.a_c2 = P(z0), L.PRO_DZ, P(coef[0]), P(coef[1]), P(coef[2])
+        d.b_pro, d.b_c0, d.b_c1 = L.PRO_AFFINE_RELU, P(scd), P(shd)
+        d.persist, d.splitk = persist, 1
+        run_igemm(d, L.KIND_WGRAD, tile=tile)
+        return dw
+
+    dw1 = wgrad(G)
+    assert_close(dw1.view(Cout, K, K, Cin).permute(0, 3, 1, 2), wr.grad, TOL, "persistent wgrad vs torch")
+    assert_close(dw1, wgrad(0), 1e-5, "persistent wgrad vs split grid")
+
+
+def _spread(sums, slots):
+    """per-channel (sum, sum2) pairs scattered over the first `slots` statistic replicas, as the producers' atomics leave them"""
+    Cc = sums.shape[0]
+    stat = torch.zeros(L.STAT_SLOTS, Cc, 2, dtype=torch.float64)
+    w = torch.rand(slots, Cc, 2, dtype=torch.float64)
+    w = w / w.sum(0, keepdim=True)
+    stat[:slots] = w * sums[None]
+    return stat.to(dev())
+
+
+def _fold(stat, slots, bwd, publish, count, gamma, **kw):
+    f = L.BnFold()
+    f.stat, f.slots, f.bwd, f.publish, f.count, f.gamma = P(stat), slots, bwd, publish, float(count), P(gamma)
+    f.eps, f.reps, f.keep = kw.get("eps", 1e-5), kw.get("reps", 1), (1.0 - 0.1) ** kw.get("reps", 1)
+    for k in ("beta", "mean", "invstd", "out0", "out1", "out2", "out3", "run_mean", "run_var", "nbt", "dgamma", "dbeta"):
+        if k in kw:
+            setattr(f, k, P(kw[k]))
+    return f
+
+
+FOLD_CONVS = [  # N, H, W, Cin, Cout, K, stride, pad, slots, tile
+    (2, 10, 10, 128, 64, 1, 1, 0, 4, 0), (3, 8, 8, 128, 128, 3, 1, 1, 2, 5), (2, 12, 12, 64, 128, 3, 2, 1, 1, 6),
+    (2, 12, 12, 64, 128, 1, 2, 0, 16, 3), (2, 9, 9, 8, 16, 3, 1, 1, 4, 0), (2, 7, 7, 256, 72, 1, 1, 0, 4, 1),
+]
+
+
+@pytest.mark.parametrize("cfg", FOLD_CONVS)
+def test_conv_with_batchnorm_folded_in_the_consumer(cfg):
+    """mmvqa_bn_fold: the consuming launch derives the BatchNorm coefficients of its A prologue from the raw sums of
+    the producer (train mode) and publishes what mmvqa_bn_coef_fwd / _bwd would have written.  Against torch's
+    BatchNorm2d (forward, running statistics with the k-fold rule, backward through the batch statistics) and against
+    the same launches fed with precomputed coefficients.  Cin = 8 takes the launcher's fallback (general loaders:
+    coefficient launch in front)."""
+    N, H, W, Cin, Cout, K, s, p, slots, tile = cfg
+    torch.manual_seed(11)
+    z1 = (torch.randn(N, Cin, H, W) * 1.5 + 0.3).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(Cin).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+    reps = 3
+    w = (torch.randn(Cout, Cin, K, K) / math.sqrt(Cin * K * K)).requires_grad_(True)
+    y = bn(z1)
+    z2 = F.conv2d(torch.relu(y), w, stride=s, padding=p)
+    OH, OW = z2.shape[2:]
+    for _ in range(reps - 1):
+        bn(z1.detach())
+    M1 = N * H * W
+    sums = torch.stack([z1.detach().double().sum(dim=(0, 2, 3)), (z1.detach().double() ** 2).sum(dim=(0, 2, 3))], 1)
+    stat = _spread(sums, slots)
+    g, b = bn.weight.detach().to(dev()), bn.bias.detach().to(dev())
+    outs = [torch.full((Cin,), float("nan"), device=dev()) for _ in range(4)]
+    rm, rv = torch.zeros(Cin, device=dev()), torch.ones(Cin, device=dev())
+    nbt = torch.zeros(1, dtype=torch.int64, device=dev())
+    xd, wd = nhwc(z1.detach()), w_ohwi(w.detach())
+    zo = torch.zeros(N * OH * OW, Cout, device=dev())
+    d, _, _ = conv_desc_fwd(xd, wd, N, H, W, Cin, Cout, K, s, p, zo)
+    d.a_pro = L.PRO_AFFINE_RELU
+    d.a_fold = _fold(stat, slots, 0, 1, M1, g, beta=b, out0=outs[0], out1=outs[1], out2=outs[2], out3=outs[3],
+                     run_mean=rm, run_var=rv, nbt=nbt, reps=reps)
+    run_igemm(d, L.KIND_FWD, tile=tile)
+    assert_close(from_nhwc(zo, N, OH, OW, Cout), z2, TOL, "conv(relu(bn(z1))) with the fold")
+    mean = z1.detach().mean(dim=(0, 2, 3))
+    invstd = 1.0 / torch.sqrt(z1.detach().var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    assert_close(outs[2], mean, 1e-5, "published mean")
+    assert_close(outs[3], invstd, 1e-5, "published invstd")
+    assert_close(outs[0], bn.weight.detach() * invstd, 1e-5, "published scale")
+    assert_close(rm, bn.running_mean, 1e-5, "running_mean (k-fold)")
+    assert_close(rv, bn.running_var, 1e-5, "running_var (k-fold)")
+    assert int(nbt) == reps
+    # ---- backward of the SECOND BatchNorm (on z2): dz2 = P*G + Q*z2 + R with P, Q, R folded from (sum G, sum G*xhat)
+    bn2 = torch.nn.BatchNorm2d(Cout).train()
+    with torch.no_grad():
+        bn2.weight.uniform_(0.5, 1.5)
+    z2d = z2.detach().requires_grad_(True)
+    G = torch.randn(N, Cout, OH, OW)
+    bn2(z2d).backward(G)
+    dz2 = z2d.grad                                   # torch's BatchNorm backward through the batch statistics
+    M2 = N * OH * OW
+    mean2 = z2.detach().mean(dim=(0, 2, 3))
+    invstd2 = 1.0 / torch.sqrt(z2.detach().var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    xhat2 = (z2.detach() - mean2[None, :, None, None]) * invstd2[None, :, None, None]
+    bs = torch.stack([G.double().sum(dim=(0, 2, 3)), (G * xhat2).double().sum(dim=(0, 2, 3))], 1)
+    bstat = _spread(bs, slots)
+    g2, m2d, i2d = bn2.weight.detach().to(dev()), mean2.to(dev()), invstd2.to(dev())
+    pqr = [torch.full((Cout,), float("nan"), device=dev()) for _ in range(3)]
+    dg, db = torch.zeros(Cout, device=dev()), torch.zeros(Cout, device=dev())
+    Gd, z2n = nhwc(G), nhwc(z2.detach())
+    # reference for the contraction: conv backward fed with torch's dz2
+    a1 = torch.relu(y.detach()).requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    F.conv2d(a1, wr, stride=s, padding=p).backward(dz2)
+    dx = torch.zeros(N * H * W, Cin, device=dev())
+    d = conv_desc_dgrad(Gd, wd, N, H, W, Cin, Cout, K, s, p, dx)
+    d.A2, d.a_pro = P(z2n), L.PRO_DZ
+    d.a_fold = _fold(bstat, slots, 1, 1, M2, g2, mean=m2d, invstd=i2d, out0=pqr[0], out1=pqr[1], out2=pqr[2], dgamma=dg, dbeta=db)
+    run_igemm(d, L.KIND_DGRAD, tile=tile)
+    assert_close(from_nhwc(dx, N, H, W, Cin), a1.grad, TOL, "dgrad through the folded BatchNorm backward")
+    assert_close(dg, bn2.weight.grad, 1e-5, "dgamma")
+    assert_close(db, bn2.bias.grad, 1e-5, "dbeta")
+    dw = torch.zeros(Cout, K * K * Cin, device=dev())
+    d = conv_desc_wgrad(Gd, xd, N, H, W, Cin, Cout, K, s, p, dw)
+    d.A2, d.a_pro = P(z2n), L.PRO_DZ
+    d.a_fold = _fold(bstat, slots, 1, 0, M2, g2, mean=m2d, invstd=i2d)
+    d.b_pro, d.b_c0, d.b_c1 = L.PRO_AFFINE_RELU, P(outs[0]), P(outs[1])
+    run_igemm(d, L.KIND_WGRAD, tile=tile if tile != 1 else 0)
+    assert_close(dw.view(Cout, K, K, Cin).permute(0, 3, 1, 2), wr.grad, TOL, "wgrad through the folded BatchNorm backward")
+    assert_close(dg, bn2.weight.grad, 1e-5, "dgamma untouched by the non-publishing launch")
+    # the same two launches on precomputed coefficients (the published P, Q, R) give the same numbers
+    dx2 = torch.zeros_like(dx)
+    d = conv_desc_dgrad(Gd, wd, N, H, W, Cin, Cout, K, s, p, dx2)
+    d.A2, d.a_pro, d.a_c0, d.a_c1, d.a_c2 = P(z2n), L.PRO_DZ, P(pqr[0]), P(pqr[1]), P(pqr[2])
+    run_igemm(d, L.KIND_DGRAD, tile=tile)
+    assert_close(dx2, dx, 1e-6, "folded vs precomputed coefficients")
+
+
+def test_block_end_with_folded_batchnorms():
+    """relu(bn3(z3) + bn_d(zd)) and relu(bn3(z3) + x) with the coefficients folded inside the block-end launch"""
+    torch.manual_seed(12)
+    for N, Cc, H, W, slots, with_d in ((3, 96, 7, 7, 4, True), (2, 256, 9, 9, 2, False), (1, 32, 5, 6, 1, True)):
+        z3, zd = torch.randn(N, Cc, H, W) * 2 + 0.5, torch.randn(N, Cc, H, W) * 0.7 - 0.2
+        b3, bd = torch.nn.BatchNorm2d(Cc).train(), torch.nn.BatchNorm2d(Cc).train()
+        with torch.no_grad():
+            for m in (b3, bd):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+        ref = torch.relu(b3(z3) + (bd(zd) if with_d else zd))
+        M = N * H * W
+        folds, keep = [], []
+        for z, m in ((z3, b3), (zd, bd)):
+            sums = torch.stack([z.double().sum(dim=(0, 2, 3)), (z.double() ** 2).sum(dim=(0, 2, 3))], 1)
+            outs = [torch.zeros(Cc, device=dev()) for _ in range(4)]
+            rm, rv = torch.zeros(Cc, device=dev()), torch.ones(Cc, device=dev())
+            nbt = torch.zeros(1, dtype=torch.int64, device=dev())
+            st, g, b = _spread(sums, slots), m.weight.detach().to(dev()), m.bias.detach().to(dev())
+            keep.append((st, g, b, outs, rm, rv, nbt))
+            folds.append(_fold(st, slots, 0, 1, M, g, beta=b, out0=outs[0], out1=outs[1], out2=outs[2], out3=outs[3],
+                               run_mean=rm, run_var=rv, nbt=nbt))
+        o = torch.zeros(M, Cc, device=dev())
+        z3d, zdd = nhwc(z3), nhwc(zd)
+        L.check(L.lib().mmvqa_bn_add_relu_fold(L.stream_ptr(), P(z3d), C.byref(folds[0]), P(zdd),
+                                               C.byref(folds[1]) if with_d else None, P(o), M, Cc))
+        torch.cuda.synchronize()
+        assert_close(from_nhwc(o, N, H, W, Cc), ref, TOL, "block end")
+        assert_close(keep[0][4], b3.running_mean, 1e-5, "bn3 running mean")
+        assert_close(keep[0][5], b3.running_var, 1e-5, "bn3 running var")
+        assert int(keep[0][6]) == 1 and int(keep[1][6]) == (1 if with_d else 0)
+        if with_d:
+            assert_close(keep[1][5], bd.running_var, 1e-5, "downsample bn running var")
+            assert_close(keep[1][3][0], bd.weight.detach() / torch.sqrt(zd.var(dim=(0, 2, 3), unbiased=False) + 1e-5), 1e-5, "bn_d scale")
+
+
 def test_maxpool():
     torch.manual_seed(6)
     N, Cc, H, W = 2, 8, 11, 12

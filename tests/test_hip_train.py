@@ -22,7 +22,9 @@ def test_mlm_loop(tmp_path):
     assert (tmp_path / "MLM" / "run.pt").exists()               # roco_train.py:194-197
     assert (tmp_path / "recorder_2.pt").exists()                # roco_train.py:164-171 (every 5 epochs)
     rec = torch.load(tmp_path / "recorder_2.pt", weights_only=False)
-    assert set(rec) == {"epoch", "optimizer", "scheduler", "scaler", "model"} and rec["epoch"] == 4
+    # the reference's five keys + which loop wrote it and its best-so-far trackers (needed for a correct --resume)
+    assert set(rec) == {"epoch", "optimizer", "scheduler", "scaler", "model", "mode", "best"} and rec["epoch"] == 4
+    assert rec["mode"] == "mlm" and rec["best"]["best"] == pytest.approx(best)
 
 
 def test_supcon_loop(tmp_path):
