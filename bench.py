@@ -300,6 +300,7 @@ def main():
         torch.cuda.synchronize()
         pr = model.profile_read()
         regs = model.profile_read_regions()
+        hbm = model.profile_read_hbm()
         model.profile(False)
         g = pr["igemm"]
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
@@ -310,9 +311,10 @@ def main():
         model.profile(False)
         ach_alone = gs["flops"] / (gs["ms"] * 1e-3) / 1e12 if gs["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
-        for name in ("round2_igemm_traffic.json", "round1_igemm_traffic.json"):
+        for name in ((f"round3_igemm_traffic_cfg{CONFIG}.json",) if CONFIG != 2 else
+                     ("round3_igemm_traffic.json", "round2_igemm_traffic.json", "round1_igemm_traffic.json")):
             tf = os.path.join(ROOT, "profiles", name)
-            if CONFIG == 2 and os.path.exists(tf):   # HBM bytes per launch from the committed rocprofv3 PMC passes
+            if os.path.exists(tf):   # HBM bytes per launch from the committed rocprofv3 PMC passes
                 traffic = json.load(open(tf))["igemm"]["hbm_bytes_per_launch"]
                 traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)"
                 break
@@ -323,9 +325,18 @@ def main():
                     single_stream=dict(achieved=ach_alone, frac=ach_alone / PEAK_F32_MFMA_TFLOPS,
                                        avg_launch_us=gs["ms"] * 1e3 / max(1, gs["launches"]),
                                        note="same step with the second HIP stream disabled: no launch shares the chip"),
-                    other_ms_per_step=dict(attention=pr["attention"]["ms"], elementwise=pr["other"]["ms"]))
+                    other_ms_per_step=dict(attention=pr["attention"]["ms"], elementwise=pr["other"]["ms"]),
+                    # matrix work outside igemm_kernel (register-resident stem tap, squeeze-excite layers: configs 3-5)
+                    matrix_outside_igemm=dict(launches=pr["matrix_other"]["launches"], ms=pr["matrix_other"]["ms"],
+                                              gflop=pr["matrix_other"]["flops"] / 1e9))
         if CONFIG in (2, 3):
             roof["blocks"] = per_block(regs, marks, model, a)
+        # the HBM-bound kernels one by one: algorithmic bytes (every tensor read / written once, fp32) over the HIP-event
+        # time of their launches in this step, against the 8 TB/s roofline
+        roof["hbm_kernels"] = {k: dict(launches=v["launches"], ms=v["ms"], algorithmic_gb=v["bytes"] / 1e9,
+                                       gbps=v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0,
+                                       frac_of_hbm_peak=(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if v["ms"] > 0 else 0.0)
+                               for k, v in hbm.items()}
 
     names = {2: ("ROCO-MLM pretrain (resnet152+transformer, bs16/GPU, 224^2, seq32)",
                  "pretrain/roco_train.py MLM-only: resnet152 + transformer(4 layers, 12 heads), num_vis 5, hidden 768, vocab "

@@ -209,6 +209,14 @@ size_t mmvqa_sizeof_model_desc(void);
 /* kind: MMVQA_KIND_*; nchw: 1 only for the 7x7 stem (NCHW image source); tile: 0 auto */
 int mmvqa_igemm(const mmvqa_gemm_desc* d, int kind, int nchw, int tile, mmvqa_stream_t s);
 int mmvqa_attention(const mmvqa_attn_desc* d, int head_dim, int backward, mmvqa_stream_t s);
+/* BertLayer forward, projection and attention in ONE launch (models/transformer.py:19-30: proj_q / proj_k / proj_v,
+ * split heads, scores / sqrt(d) - 10000 (1 - mask), softmax, dropout, @ v, merge heads) for T <= 32 and head dimension 64
+ * (hidden = 64 * heads): xn [B*T, hidden] -> qkv [B*T, 3*hidden] (q | k | v, kept for the backward pass),
+ * probs [B, heads, T(key), T(query)] (before dropout), ctx [B*T, hidden].  W = the three projection weights back to back
+ * [3*hidden, hidden], bias [3*hidden] or NULL.  Same dropout stream as mmvqa_attention with the same seed. */
+int mmvqa_qkv_attention_fwd(mmvqa_stream_t s, const float* xn, const float* W, const float* bias, const long long* mask,
+                            float* qkv, float* probs, float* ctx, int B, int T, int hidden, int heads, float drop_p,
+                            uint32_t seed);
 
 /* BatchNorm2d (train: batch stats + running update repeated `reps` times; eval: running stats) */
 int mmvqa_bn_coef_fwd(mmvqa_stream_t s, const double* stat, int C, double count, float eps, const float* gamma,
@@ -381,6 +389,11 @@ int mmvqa_engine_profile_read(mmvqa_engine* e, int cls, long long* launches, dou
  * 154-166), 6 embeddings, 7 BatchNorm coefficient kernels */
 int mmvqa_engine_profile_read_region(mmvqa_engine* e, int region, int cls, long long* launches, double* ms,
                                      double* flops);
+/* the HBM-bound kernels of the profiled step one by one: launches, total ms and ALGORITHMIC bytes (every tensor the
+ * kernel has to read or write, once, fp32) -- bytes / ms against the 8 TB/s roofline.  kernel: 1 bn_add_relu (block end),
+ * 2 / 3 maxpool fwd / bwd, 4 / 5 layernorm fwd / bwd, 6 dropout_copy, 7 bn_act_add, 8 / 9 / 10 dwconv fwd / bwd_data /
+ * bwd_weight, 11 se_pool, 12 se_dgate, 13 act_bwd_stats, 14 / 15 tap_thin fwd / bwd */
+int mmvqa_engine_profile_read_hbm(mmvqa_engine* e, int kernel, long long* launches, double* ms, double* bytes);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Device input pipeline: the torchvision/PIL transforms of pretrain/roco_train.py:98-112 and

@@ -103,6 +103,7 @@ SIGNATURES = {
     "mmvqa_sizeof_model_desc": (_sz, []),
     "mmvqa_igemm": (_i, [C.POINTER(GemmDesc), _i, _i, _i, _P]),
     "mmvqa_attention": (_i, [C.POINTER(AttnDesc), _i, _i, _P]),
+    "mmvqa_qkv_attention_fwd": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _f, _u32]),
     "mmvqa_bn_coef_fwd": (_i, [_P, _P, _i, _d, _f, _P, _P, _P, _P, _P, _f, _i, _i, _P, _P, _P, _P]),
     "mmvqa_bn_coef_bwd": (_i, [_P, _P, _i, _d, _P, _P, _P, _i, _P, _P, _P, _P, _P]),
     "mmvqa_bn_add_relu": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _l, _i]),
@@ -162,6 +163,7 @@ SIGNATURES = {
     "mmvqa_engine_profile": (_i, [_P, _i]),
     "mmvqa_engine_profile_read": (_i, [_P, _i, C.POINTER(_ll), C.POINTER(_d), C.POINTER(_d)]),
     "mmvqa_engine_profile_read_region": (_i, [_P, _i, _i, C.POINTER(_ll), C.POINTER(_d), C.POINTER(_d)]),
+    "mmvqa_engine_profile_read_hbm": (_i, [_P, _i, C.POINTER(_ll), C.POINTER(_d), C.POINTER(_d)]),
 }
 
 _lib = None

@@ -58,6 +58,12 @@ int mmvqa_attention(const mmvqa_attn_desc* d, int head_dim, int backward, mmvqa_
   return mmvqa_launch_attention(*d, head_dim, backward, ST(s));
 }
 
+int mmvqa_qkv_attention_fwd(mmvqa_stream_t s, const float* xn, const float* W, const float* bias, const long long* mask,
+                            float* qkv, float* probs, float* ctx, int B, int T, int hidden, int heads, float drop_p,
+                            uint32_t seed) {
+  if (B <= 0 || drop_p < 0.f || drop_p >= 1.f) return mmvqa_set_error(MMVQA_ERR_ARG, "qkv_attention_fwd: B=%d drop_p=%g", B, (double)drop_p);
+  return k_qkv_attn_fwd(ST(s), xn, W, bias, mask, qkv, probs, ctx, B, T, hidden, heads, drop_p, seed);
+}
 int mmvqa_bn_coef_fwd(mmvqa_stream_t s, const double* stat, int C, double count, float eps, const float* gamma,
                       const float* beta, float* run_mean, float* run_var, long long* nbt, float momentum, int reps,
                       int training, float* scale, float* shift, float* mean, float* invstd) {
@@ -294,6 +300,9 @@ int mmvqa_engine_profile(mmvqa_engine* e, int enable) {
     memset(e->reg_launch, 0, sizeof(e->reg_launch));
     memset(e->reg_ms, 0, sizeof(e->reg_ms));
     memset(e->reg_flops, 0, sizeof(e->reg_flops));
+    memset(e->tag_launch, 0, sizeof(e->tag_launch));
+    memset(e->tag_ms, 0, sizeof(e->tag_ms));
+    memset(e->tag_bytes, 0, sizeof(e->tag_bytes));
   }
   return MMVQA_OK;
 }
@@ -306,6 +315,15 @@ int mmvqa_engine_profile_read_region(mmvqa_engine* e, int region, int cls, long 
   if (launches) *launches = e->reg_launch[region][cls];
   if (ms) *ms = e->reg_ms[region][cls];
   if (flops) *flops = e->reg_flops[region][cls];
+  return MMVQA_OK;
+}
+int mmvqa_engine_profile_read_hbm(mmvqa_engine* e, int kernel, long long* launches, double* ms, double* bytes) {
+  if (!e || kernel <= HB_NONE || kernel >= HB_N) return mmvqa_set_error(MMVQA_ERR_ARG, "profile_read_hbm: bad kernel id");
+  int r = engine_profile_collect(e);
+  if (r != MMVQA_OK) return r;
+  if (launches) *launches = e->tag_launch[kernel];
+  if (ms) *ms = e->tag_ms[kernel];
+  if (bytes) *bytes = e->tag_bytes[kernel];
   return MMVQA_OK;
 }
 int mmvqa_engine_profile_read(mmvqa_engine* e, int cls, long long* launches, double* ms, double* flops) {

@@ -1831,8 +1831,8 @@ int k_dwconv_fwd(hipStream_t st, const float* z1, const float* s1, const float* 
   if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
   const size_t sm = (size_t)H * W * 128 + 256 * 8 * sizeof(double);
   if (sm <= DW_TILE_MAX_BYTES && !dw_pixel_form()) {
-    static bool attr = false;
-    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_fwd_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES)); attr = true; }
+    // (every launch: the attribute is per device and the call is cheap -- a once-per-process flag left a second device without it)
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_fwd_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES));
     hipLaunchKernelGGL(dwconv_fwd_tile_kernel, dim3(C / 32, N), dim3(256), sm, st, z1, s1, b1, w, z2, stat, H, W, C, OH, OW,
                        stride, pad);
     KERNEL_CHECK_RET();
@@ -1851,8 +1851,8 @@ int k_dwconv_bwd_data(hipStream_t st, const float* g2, const float* z2, const fl
   if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
   const size_t sm = (size_t)OH * OW * 128 + 256 * 8 * sizeof(double);
   if (sm <= DW_TILE_MAX_BYTES && !dw_pixel_form()) {
-    static bool attr = false;
-    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_bwd_data_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES)); attr = true; }
+    // (every launch: the attribute is per device and the call is cheap -- a once-per-process flag left a second device without it)
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_bwd_data_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES));
     hipLaunchKernelGGL(dwconv_bwd_data_tile_kernel, dim3(C / 32, N), dim3(256), sm, st, g2, z2, P, Q, R, w, z1, s1, b1,
                        mean1, invstd1, g1, stat, H, W, C, OH, OW, stride, pad);
     KERNEL_CHECK_RET();
@@ -1870,8 +1870,8 @@ int k_dwconv_bwd_weight(hipStream_t st, const float* g2, const float* z2, const 
   if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
   const size_t sm = ((size_t)H * W + (size_t)OH * OW) * 128 + 32 * 8 * 36 * sizeof(float);
   if (sm <= DW_TILE_MAX_BYTES && !dw_pixel_form()) {
-    static bool attr = false;
-    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_bwd_weight_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES)); attr = true; }
+    // (every launch: the attribute is per device and the call is cheap -- a once-per-process flag left a second device without it)
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_bwd_weight_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES));
     hipLaunchKernelGGL(dwconv_bwd_weight_tile_kernel, dim3(C / 32, N), dim3(256), sm, st, g2, z2, P, Q, R, z1, s1, b1, dw, H, W,
                        C, OH, OW, stride, pad);
     KERNEL_CHECK_RET();

@@ -323,6 +323,10 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
         max_mid = std::max(max_mid, std::max(Min, Mout) * blk.mid);
         max_se = std::max(max_se, (size_t)B * blk.mid);
         max_separt = std::max(max_separt, k_se_fc_bwd_scratch_floats(B, blk.mid, blk.rd));
+        if (!k_se_fc_bwd_ok(blk.rd)) {   // refuse here, not at the first backward
+          mmvqa_set_error(MMVQA_ERR_ARG, "plan: squeeze-excite reduce width %d exceeds what se_fc_bwd supports", blk.rd);
+          return 0;
+        }
       }
       blk.out = a.f(Mout * blk.cout);
       max_io = std::max(max_io, std::max(Min * blk.cin, Mout * blk.cout));
@@ -456,12 +460,12 @@ static inline double* stat_ptr(mmvqa_engine* e, size_t doff) {
   return reinterpret_cast<double*>(e->ws + e->statzone) + doff;
 }
 
-static int prof_begin(mmvqa_engine* e, hipStream_t st, int cls, double flops) {
+static int prof_begin(mmvqa_engine* e, hipStream_t st, int cls, double flops, int tag = HB_NONE, double bytes = 0.0) {
   if (!e->prof_on) return MMVQA_OK;
   mmvqa_engine::ProfRec r;
   HIP_CHECK_RET(hipEventCreate(&r.a));
   HIP_CHECK_RET(hipEventCreate(&r.b));
-  r.cls = cls; r.reg = e->prof_reg; r.flops = flops;
+  r.cls = cls; r.reg = e->prof_reg; r.flops = flops; r.tag = tag; r.bytes = bytes;
   HIP_CHECK_RET(hipEventRecord(r.a, st));
   e->prof.push_back(r);
   return MMVQA_OK;
@@ -477,6 +481,13 @@ struct RegScope {   // tags the launches of a scope with a profiler region
   ~RegScope() { e->prof_reg = old; }
 };
 #define REG(r) RegScope _reg_scope(e, r)
+// an HBM-bound launch: `bytes` = the tensors it has to read and write once (algorithmic bytes, fp32)
+#define RUNB(tag, bytes, call)                             \
+  do {                                                     \
+    TRY(prof_begin(e, st, PROF_OTHER, 0, tag, (double)(bytes))); \
+    TRY(call);                                             \
+    TRY(prof_end(e, st));                                  \
+  } while (0)
 #define RUN(cls, flops, call)          \
   do {                                 \
     TRY(prof_begin(e, st, cls, flops)); \
@@ -581,13 +592,13 @@ static int lin_wgrad(mmvqa_engine* e, hipStream_t st, const float* dy, int dy_ld
 
 static int ln_fwd(mmvqa_engine* e, hipStream_t st, const float* x, const LNRef& ln, float* y, float* mean,
                   float* rstd, long rows, float eps) {
-  RUN(PROF_OTHER, 0, k_layernorm_fwd(st, x, nullptr, PRM(ln.g), PRM(ln.b), y, nullptr, mean, rstd, (int)rows,
+  RUNB(HB_LAYERNORM_FWD, 8.0 * rows * e->d.hidden, k_layernorm_fwd(st, x, nullptr, PRM(ln.g), PRM(ln.b), y, nullptr, mean, rstd, (int)rows,
                                      e->d.hidden, eps));
   return MMVQA_OK;
 }
 static int ln_bwd(mmvqa_engine* e, hipStream_t st, const float* dy, const float* x, const LNRef& ln,
                   const float* mean, const float* rstd, const float* dres, float* dx, long rows) {
-  RUN(PROF_OTHER, 0, k_layernorm_bwd(st, dy, x, PRM(ln.g), mean, rstd, dres, dx, GRD(ln.g), GRD(ln.b), (int)rows,
+  RUNB(HB_LAYERNORM_BWD, (dres ? 16.0 : 12.0) * rows * e->d.hidden, k_layernorm_bwd(st, dy, x, PRM(ln.g), mean, rstd, dres, dx, GRD(ln.g), GRD(ln.b), (int)rows,
                                      e->d.hidden));
   return MMVQA_OK;
 }
@@ -712,9 +723,11 @@ static int tap_fwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, co
   // (C = 64 with BatchNorm+ReLU on load needs 256 VGPRs there and only ties the GEMM kernel: measured, round 2)
   if (!thin_off && t.C <= 32 && k_tap_thin_ok(t.M, e->d.hidden, t.C, t.HW)) {
     // few channels, huge map (EfficientNet's stem tap): weights stay in registers, no tile machinery (tapthin.hip)
-    RUN(PROF_OTHER, 0, k_tap_thin_fwd(st, fmap, bn_in ? WS(bn_in->scale) : nullptr, bn_in ? WS(bn_in->shift) : nullptr,
+    TRY(prof_begin(e, st, PROF_MATRIX, 2.0 * (double)t.M * e->d.hidden * t.C, HB_TAP_THIN_FWD, 4.0 * (double)t.M * t.C));
+    TRY(k_tap_thin_fwd(st, fmap, bn_in ? WS(bn_in->scale) : nullptr, bn_in ? WS(bn_in->shift) : nullptr,
                                       PRM(t.w), WS(e->vis) + (size_t)k * e->B * e->d.hidden, t.M, e->d.hidden, t.C, t.HW,
                                       tap_act(e)));
+    TRY(prof_end(e, st));
     return MMVQA_OK;
   }
   GemmParams g = gp_linear_geom();
@@ -747,9 +760,12 @@ static int tap_bwd(mmvqa_engine* e, hipStream_t st, int k, const float* fmap, co
   set_sk(e, st, g);
   static const bool thin_off = getenv("MMVQA_NO_TAP_THIN") != nullptr;
   if (!thin_off && t.C <= 32 && k_tap_thin_ok(t.M, Hd, t.C, t.HW))   // EfficientNet stem tap: recompute in registers (tapthin.hip)
-    RUN(PROF_OTHER, 0, k_tap_thin_bwd(st, fmap, bn_in ? WS(bn_in->scale) : nullptr, bn_in ? WS(bn_in->shift) : nullptr,
-                                      PRM(t.w), g.tap_dv, WS(e->du), t.M, Hd, t.C, t.HW, tap_act(e)));
-  else
+  {
+    TRY(prof_begin(e, st, PROF_MATRIX, 2.0 * (double)t.M * Hd * t.C, HB_TAP_THIN_BWD, 4.0 * (double)t.M * (t.C + Hd)));
+    TRY(k_tap_thin_bwd(st, fmap, bn_in ? WS(bn_in->scale) : nullptr, bn_in ? WS(bn_in->shift) : nullptr,
+                       PRM(t.w), g.tap_dv, WS(e->du), t.M, Hd, t.C, t.HW, tap_act(e)));
+    TRY(prof_end(e, st));
+  } else
     RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
   // dW_tap[Hd][C] += du^T fmap
   GemmParams w = gp_linear_geom();
@@ -853,7 +869,7 @@ static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
   SideCtx sc(e, st);
   sc.fork();
   TRY(tap_fwd(e, sc.sd, 4, WS(e->z0), &e->stem_bn));
-  RUN(PROF_OTHER, 0, k_maxpool_fwd(st, WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), WS(e->p0),
+  RUNB(HB_MAXPOOL_FWD, 4.0 * B * e->SH * e->SW * w + 5.0 * B * e->PH * e->PW * w, k_maxpool_fwd(st, WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), WS(e->p0),
                                    reinterpret_cast<unsigned char*>(WS(e->pool_idx)), B, e->SH, e->SW, w, e->PH,
                                    e->PW));
   const float* x = WS(e->p0);
@@ -874,14 +890,14 @@ static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
       mmvqa_bn_fold f3, fd;
       set_fold_fwd(e, f3, b.b3);
       if (b.has_ds) { sc.need(ev_ds); set_fold_fwd(e, fd, b.bd); }
-      RUN(PROF_OTHER, 0, k_bn_add_relu_fold(st, WS(b.z3), &f3, b.has_ds ? WS(b.zd) : x, b.has_ds ? &fd : nullptr,
+      RUNB(HB_BN_ADD_RELU, 12.0 * rows * b.c3.Cout, k_bn_add_relu_fold(st, WS(b.z3), &f3, b.has_ds ? WS(b.zd) : x, b.has_ds ? &fd : nullptr,
                                             WS(b.out), rows, b.c3.Cout));
     } else if (b.has_ds) {
       sc.need(ev_ds);
-      RUN(PROF_OTHER, 0, k_bn_add_relu(st, WS(b.z3), WS(b.b3.scale), WS(b.b3.shift), WS(b.zd), WS(b.bd.scale),
+      RUNB(HB_BN_ADD_RELU, 12.0 * rows * b.c3.Cout, k_bn_add_relu(st, WS(b.z3), WS(b.b3.scale), WS(b.b3.shift), WS(b.zd), WS(b.bd.scale),
                                        WS(b.bd.shift), WS(b.out), rows, b.c3.Cout));
     } else {
-      RUN(PROF_OTHER, 0, k_bn_add_relu(st, WS(b.z3), WS(b.b3.scale), WS(b.b3.shift), x, nullptr, nullptr,
+      RUNB(HB_BN_ADD_RELU, 12.0 * rows * b.c3.Cout, k_bn_add_relu(st, WS(b.z3), WS(b.b3.scale), WS(b.b3.shift), x, nullptr, nullptr,
                                        WS(b.out), rows, b.c3.Cout));
     }
     x = WS(b.out);
@@ -999,7 +1015,7 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
   float* g0 = WS(e->gbuf[cur ^ 1]);
   sc.need(ev_prevG);
   sc.need(ev_tap[4]);
-  RUN(PROF_OTHER, 0,
+  RUNB(HB_MAXPOOL_BWD, 12.0 * B * e->SH * e->SW * w + 5.0 * B * e->PH * e->PW * w,
       k_maxpool_bwd(st, WS(e->gbuf[cur]), reinterpret_cast<unsigned char*>(WS(e->pool_idx)), WS(e->tapgrad[4]),
                     WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), WS(e->stem_bn.mean),
                     WS(e->stem_bn.invstd), g0, stat_ptr(e, e->stem_bn.stat_b), B, e->SH, e->SW, w, e->PH, e->PW));
@@ -1084,7 +1100,7 @@ static int effnet_forward(mmvqa_engine* e, hipStream_t st) {
     if (e->training) g.stat1 = stat_ptr(e, e->stem_bn.stat_f);
     RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 1, 0, st));
     TRY(bn_coef_fwd(e, st, e->stem_bn));
-    RUN(PROF_OTHER, 0, k_bn_act_add(st, WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), ACT_SILU, nullptr, nullptr,
+    RUNB(HB_BN_ACT_ADD, 8.0 * M0 * 24, k_bn_act_add(st, WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), ACT_SILU, nullptr, nullptr,
                                     nullptr, 0, ACT_NONE, WS(e->eff_a0), M0, 24));
   }
   const float* x = WS(e->eff_a0);
@@ -1093,27 +1109,27 @@ static int effnet_forward(mmvqa_engine* e, hipStream_t st) {
     const float* idn = b.skip ? x : nullptr;
     if (b.type == 0) {
       TRY(eff_conv_fwd(e, st, b.c_a, x, nullptr, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.za), b.b_a));
-      RUN(PROF_OTHER, 0, k_bn_act_add(st, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), ACT_SILU, idn, nullptr, nullptr, 0,
+      RUNB(HB_BN_ACT_ADD, (idn ? 12.0 : 8.0) * Mout * b.cout, k_bn_act_add(st, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), ACT_SILU, idn, nullptr, nullptr, 0,
                                       ACT_NONE, WS(b.out), Mout, b.cout));
     } else if (b.type == 1) {
       TRY(eff_conv_fwd(e, st, b.c_a, x, nullptr, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.za), b.b_a));
       TRY(eff_conv_fwd(e, st, b.c_p, WS(b.za), &b.b_a, nullptr, B, b.OH, b.OW, b.OH, b.OW, WS(b.zp), b.b_p));
-      RUN(PROF_OTHER, 0, k_bn_act_add(st, WS(b.zp), WS(b.b_p.scale), WS(b.b_p.shift), ACT_NONE, idn, nullptr, nullptr, 0,
+      RUNB(HB_BN_ACT_ADD, (idn ? 12.0 : 8.0) * Mout * b.cout, k_bn_act_add(st, WS(b.zp), WS(b.b_p.scale), WS(b.b_p.shift), ACT_NONE, idn, nullptr, nullptr, 0,
                                       ACT_NONE, WS(b.out), Mout, b.cout));
     } else {
       TRY(eff_conv_fwd(e, st, b.c_a, x, nullptr, nullptr, B, b.H, b.W, b.H, b.W, WS(b.za), b.b_a));
-      RUN(PROF_OTHER, 0, k_dwconv_fwd(st, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), PRM(b.dw_w), WS(b.zdw),
+      RUNB(HB_DWCONV_FWD, 4.0 * ((double)B * b.H * b.W + (double)Mout) * b.mid, k_dwconv_fwd(st, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), PRM(b.dw_w), WS(b.zdw),
                                       e->training ? stat_ptr(e, b.b_dw.stat_f) : nullptr, B, b.H, b.W, b.mid, b.OH, b.OW,
                                       b.stride, b.pad));
       TRY(bn_coef_fwd(e, st, b.b_dw));
       // squeeze-excite: gate = sigmoid(W_e silu(W_r mean_hw(a2) + b_r) + b_e)
-      RUN(PROF_OTHER, 0, k_se_pool(st, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift), WS(b.pool), B, b.OH * b.OW, b.mid));
-      RUN(PROF_OTHER, 0, k_skinny_fwd(st, WS(b.pool), b.mid, PRM(b.se_r.w), PRM(b.se_r.b), ACT_SILU, WS(b.rpre), WS(b.r),
+      RUNB(HB_SE_POOL, 4.0 * Mout * b.mid, k_se_pool(st, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift), WS(b.pool), B, b.OH * b.OW, b.mid));
+      RUN(PROF_MATRIX, 2.0 * B * b.mid * b.rd, k_skinny_fwd(st, WS(b.pool), b.mid, PRM(b.se_r.w), PRM(b.se_r.b), ACT_SILU, WS(b.rpre), WS(b.r),
                                       B, b.rd, b.mid));
-      RUN(PROF_OTHER, 0, k_skinny_fwd(st, WS(b.r), b.rd, PRM(b.se_e.w), PRM(b.se_e.b), ACT_SIGMOID, WS(b.gpre),
+      RUN(PROF_MATRIX, 2.0 * B * b.mid * b.rd, k_skinny_fwd(st, WS(b.r), b.rd, PRM(b.se_e.w), PRM(b.se_e.b), ACT_SIGMOID, WS(b.gpre),
                                       WS(b.gate), B, b.mid, b.rd));
       TRY(eff_conv_fwd(e, st, b.c_p, WS(b.zdw), &b.b_dw, WS(b.gate), B, b.OH, b.OW, b.OH, b.OW, WS(b.zp), b.b_p));
-      RUN(PROF_OTHER, 0, k_bn_act_add(st, WS(b.zp), WS(b.b_p.scale), WS(b.b_p.shift), ACT_NONE, idn, nullptr, nullptr, 0,
+      RUNB(HB_BN_ACT_ADD, (idn ? 12.0 : 8.0) * Mout * b.cout, k_bn_act_add(st, WS(b.zp), WS(b.b_p.scale), WS(b.b_p.shift), ACT_NONE, idn, nullptr, nullptr, 0,
                                       ACT_NONE, WS(b.out), Mout, b.cout));
     }
     x = WS(b.out);
@@ -1156,7 +1172,7 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
     const float* dz_first = nullptr;   // gradient tensor feeding the block's first convolution
     if (b.type == 0) {
       // out = silu(bn(za)) + x
-      RUN(PROF_OTHER, 0, k_act_bwd_stats(st, G, nullptr, nullptr, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift),
+      RUNB(HB_ACT_BWD_STATS, 12.0 * Mout * b.cout, k_act_bwd_stats(st, G, nullptr, nullptr, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift),
                                          WS(b.b_a.mean), WS(b.b_a.invstd), ACT_SILU, gA, stat_ptr(e, b.b_a.stat_b), Mout,
                                          b.OH * b.OW, b.cout));
       dz_first = gA;
@@ -1174,20 +1190,20 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
       TRY(conv_dgrad(e, st, b.c_p, G, WS(b.zp), b.b_p, B, b.OH, b.OW, b.OH, b.OW, gA, EpiOpt()));   // t = d(a2*gate)
       // squeeze-excite backward
       float* dgate = WS(e->eff_se[0]); float* dpool = WS(e->eff_se[3]);
-      RUN(PROF_OTHER, 0, k_se_dgate(st, gA, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift), dgate, B, b.OH * b.OW, b.mid,
+      RUNB(HB_SE_DGATE, 8.0 * Mout * b.mid, k_se_dgate(st, gA, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift), dgate, B, b.OH * b.OW, b.mid,
                                     WS(e->eff_separt), B * b.rd));
-      RUN(PROF_OTHER, 0, k_se_fc_bwd(st, dgate, WS(b.gpre), WS(b.r), WS(b.rpre), WS(b.pool), PRM(b.se_e.w), PRM(b.se_r.w),
+      RUN(PROF_MATRIX, 8.0 * B * b.mid * b.rd, k_se_fc_bwd(st, dgate, WS(b.gpre), WS(b.r), WS(b.rpre), WS(b.pool), PRM(b.se_e.w), PRM(b.se_r.w),
                                      GRD(b.se_e.w), GRD(b.se_e.b), GRD(b.se_r.w), GRD(b.se_r.b), dpool,
                                      WS(e->eff_separt), 1, B, b.mid, b.rd));
       // du2 = (t*gate + dpool/HW) * silu'(bn2(zdw)); BN2 sums
-      RUN(PROF_OTHER, 0, k_act_bwd_stats(st, gA, WS(b.gate), dpool, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift),
+      RUNB(HB_ACT_BWD_STATS, 12.0 * Mout * b.mid, k_act_bwd_stats(st, gA, WS(b.gate), dpool, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift),
                                          WS(b.b_dw.mean), WS(b.b_dw.invstd), ACT_SILU, gB, stat_ptr(e, b.b_dw.stat_b), Mout,
                                          b.OH * b.OW, b.mid));
       TRY(bn_coef_bwd(e, st, b.b_dw));
-      RUN(PROF_OTHER, 0, k_dwconv_bwd_weight(st, gB, WS(b.zdw), WS(b.b_dw.P), WS(b.b_dw.Q), WS(b.b_dw.R), WS(b.za),
+      RUNB(HB_DWCONV_BWD_WEIGHT, 4.0 * (2.0 * Mout + (double)Min) * b.mid, k_dwconv_bwd_weight(st, gB, WS(b.zdw), WS(b.b_dw.P), WS(b.b_dw.Q), WS(b.b_dw.R), WS(b.za),
                                              WS(b.b_a.scale), WS(b.b_a.shift), GRD(b.dw_w), B, b.H, b.W, b.mid, b.OH, b.OW,
                                              b.stride, b.pad));
-      RUN(PROF_OTHER, 0, k_dwconv_bwd_data(st, gB, WS(b.zdw), WS(b.b_dw.P), WS(b.b_dw.Q), WS(b.b_dw.R), PRM(b.dw_w),
+      RUNB(HB_DWCONV_BWD_DATA, 4.0 * (2.0 * Mout + 2.0 * (double)Min) * b.mid, k_dwconv_bwd_data(st, gB, WS(b.zdw), WS(b.b_dw.P), WS(b.b_dw.Q), WS(b.b_dw.R), PRM(b.dw_w),
                                            WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), WS(b.b_a.mean), WS(b.b_a.invstd), gA,
                                            stat_ptr(e, b.b_a.stat_b), B, b.H, b.W, b.mid, b.OH, b.OW, b.stride, b.pad));
       dz_first = gA;
@@ -1208,7 +1224,7 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
   // stem: du0 = G(a0) * silu'(bn1(z0)); BN sums; 3x3 weight gradient on the NCHW image
   float* g0 = WS(e->gbuf[cur ^ 1]);
   const long M0 = (long)B * e->SH * e->SW;
-  RUN(PROF_OTHER, 0, k_act_bwd_stats(st, WS(e->gbuf[cur]), nullptr, nullptr, WS(e->z0), WS(e->stem_bn.scale),
+  RUNB(HB_ACT_BWD_STATS, 12.0 * M0 * 24, k_act_bwd_stats(st, WS(e->gbuf[cur]), nullptr, nullptr, WS(e->z0), WS(e->stem_bn.scale),
                                      WS(e->stem_bn.shift), WS(e->stem_bn.mean), WS(e->stem_bn.invstd), ACT_SILU, g0,
                                      stat_ptr(e, e->stem_bn.stat_b), M0, e->SH * e->SW, 24));
   TRY(bn_coef_bwd(e, st, e->stem_bn));
@@ -1251,6 +1267,15 @@ static int bert_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, cons
   for (int i = 0; i < d.n_layers; ++i) {
     BertLayerRef& L = e->bert[i];
     TRY(ln_fwd(e, st, x, e->norm1, WS(L.xn1), WS(L.mean1), WS(L.rstd1), M, 1e-12f));
+    static const bool fused_off = getenv("MMVQA_NO_FUSED_QKV") != nullptr;   // A/B switch
+    if (!fused_off && k_qkv_attn_fwd_ok(e->T, H, d.heads)) {
+      // projection + attention of every (sample, head) in one launch (qkvattn.hip); its matrix work is booked under the
+      // attention region: the north-star block = QKV products + attention, whichever launch carries them
+      REG(REG_ATTN);
+      RUN(PROF_ATTN, 2.0 * M * 3 * H * H + 4.0 * e->B * d.heads * (double)e->T * e->T * (H / d.heads),
+          k_qkv_attn_fwd(st, WS(L.xn1), PRM(L.qkv.w), PRM(L.qkv.b), e->mask, WS(L.qkvo), WS(L.probs), WS(L.ctx), e->B, e->T,
+                         H, d.heads, p, site_seed(e, i, 0)));
+    } else {
     { REG(REG_QKV); TRY(lin_fwd(e, st, WS(L.xn1), H, M, L.qkv, WS(L.qkvo), 3 * H, ACT_NONE, nullptr, 0.f, 0, nullptr, 0)); }
     AttnParams a;
     memset(&a, 0, sizeof(a));
@@ -1261,6 +1286,7 @@ static int bert_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, cons
     a.B = e->B; a.T = e->T; a.heads = d.heads; a.sqrt_d = sqrtf((float)(H / d.heads));
     a.drop_p = p; a.seed = site_seed(e, i, 0);
     TRY(attn_call(e, st, a, H / d.heads, 0));
+    }
     TRY(lin_fwd(e, st, WS(L.ctx), H, M, L.proj, WS(L.y), H, ACT_NONE, nullptr, p, site_seed(e, i, 1), x, H));
     TRY(ln_fwd(e, st, WS(L.y), e->norm1, WS(L.xn2), WS(L.mean2), WS(L.rstd2), M, 1e-12f));
     TRY(lin_fwd(e, st, WS(L.xn2), H, M, L.fc1, WS(L.h1), 4 * H, ACT_GELU, WS(L.pre1), 0.f, 0, nullptr, 0));
@@ -1285,7 +1311,7 @@ static int bert_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
     // FFN branch: z = y + drop(fc2(gelu(fc1(norm1(y)))))
     const float* dzd = dz;
     if (p > 0.f) {
-      RUN(PROF_OTHER, 0, k_dropout_copy(st, dz, WS(e->t_b), M * H, p, site_seed(e, i, 2)));
+      RUNB(HB_DROPOUT_COPY, 8.0 * M * H, k_dropout_copy(st, dz, WS(e->t_b), M * H, p, site_seed(e, i, 2)));
       dzd = WS(e->t_b);
     }
     TRY(lin_wgrad(e, st, dzd, H, WS(L.h1), 4 * H, M, L.fc2, true));
@@ -1298,7 +1324,7 @@ static int bert_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
     // attention branch: y = x + drop(proj(attn(norm1(x))))
     const float* dyd = dy;
     if (p > 0.f) {
-      RUN(PROF_OTHER, 0, k_dropout_copy(st, dy, WS(e->t_b), M * H, p, site_seed(e, i, 1)));
+      RUNB(HB_DROPOUT_COPY, 8.0 * M * H, k_dropout_copy(st, dy, WS(e->t_b), M * H, p, site_seed(e, i, 1)));
       dyd = WS(e->t_b);
     }
     TRY(lin_wgrad(e, st, dyd, H, WS(L.ctx), H, M, L.proj, true));
@@ -1371,7 +1397,7 @@ static int rf_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
     float* ds2 = WS(e->t_d);
     const float* dff = ds2;
     if (p > 0.f) {
-      RUN(PROF_OTHER, 0, k_dropout_copy(st, ds2, WS(e->t_b), M * H, p, site_seed(e, i, 2)));
+      RUNB(HB_DROPOUT_COPY, 8.0 * M * H, k_dropout_copy(st, ds2, WS(e->t_b), M * H, p, site_seed(e, i, 2)));
       dff = WS(e->t_b);
     }
     TRY(lin_wgrad(e, st, dff, H, WS(L.hact), 4 * H, M, L.ff2, true));
@@ -1383,7 +1409,7 @@ static int rf_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
     float* ds1 = WS(e->t_d);
     const float* dr = ds1;
     if (p > 0.f) {
-      RUN(PROF_OTHER, 0, k_dropout_copy(st, ds1, WS(e->t_b), M * H, p, site_seed(e, i, 1)));
+      RUNB(HB_DROPOUT_COPY, 8.0 * M * H, k_dropout_copy(st, ds1, WS(e->t_b), M * H, p, site_seed(e, i, 1)));
       dr = WS(e->t_b);
     }
     TRY(lin_wgrad(e, st, dr, H, WS(L.res), H, M, L.proj, false));
@@ -1580,6 +1606,7 @@ int engine_profile_collect(mmvqa_engine* e) {
     e->reg_launch[r.reg][r.cls] += 1;
     e->reg_ms[r.reg][r.cls] += ms;
     e->reg_flops[r.reg][r.cls] += r.flops;
+    if (r.tag > HB_NONE && r.tag < HB_N) { e->tag_launch[r.tag] += 1; e->tag_ms[r.tag] += ms; e->tag_bytes[r.tag] += r.bytes; }
     hipEventDestroy(r.a);
     hipEventDestroy(r.b);
   }

@@ -84,10 +84,17 @@ struct RFLayerRef {
   size_t kqvo, probs, prev, res, s1, x1, mean1, rstd1, pre, hact, s2, x2, mean2, rstd2;
 };
 
-enum { PROF_IGEMM = 0, PROF_ATTN = 1, PROF_OTHER = 2, PROF_NCLS = 3 };
+// launch classes of the profiler: igemm_kernel | attention | everything else without matrix work | matrix work OUTSIDE
+// igemm_kernel (the register-resident stem tap of tapthin.hip, the squeeze-excite fully connected layers of se.hip)
+enum { PROF_IGEMM = 0, PROF_ATTN = 1, PROF_OTHER = 2, PROF_MATRIX = 3, PROF_NCLS = 4 };
 // profiler regions (per-block rooflines): which part of the step a launch belongs to
 enum { REG_BACKBONE = 0, REG_TAP = 1, REG_QKV = 2, REG_ATTN = 3, REG_ENC = 4, REG_HEAD = 5, REG_EMBED = 6,
        REG_BNCOEF = 7, REG_N = 8 };
+
+// HBM-bound kernels the profiler reports one by one (algorithmic bytes / measured time against the 8 TB/s roofline)
+enum { HB_NONE = 0, HB_BN_ADD_RELU, HB_MAXPOOL_FWD, HB_MAXPOOL_BWD, HB_LAYERNORM_FWD, HB_LAYERNORM_BWD, HB_DROPOUT_COPY,
+       HB_BN_ACT_ADD, HB_DWCONV_FWD, HB_DWCONV_BWD_DATA, HB_DWCONV_BWD_WEIGHT, HB_SE_POOL, HB_SE_DGATE, HB_ACT_BWD_STATS,
+       HB_TAP_THIN_FWD, HB_TAP_THIN_BWD, HB_N };
 
 constexpr size_t SK_WS_FLOATS = (size_t)8 << 20;   // 32 MB: 8 splits of a 224-tile (64x64) product
 constexpr int SK_CNT_N = 16384;                    // tiles a persistent launch may have (one arrival ticket each)
@@ -161,7 +168,9 @@ struct mmvqa_engine {
   // ---- profiling
   int prof_on = 0;
   int prof_reg = REG_BACKBONE;
-  struct ProfRec { hipEvent_t a, b; int cls, reg; double flops; };
+  struct ProfRec { hipEvent_t a, b; int cls, reg; double flops; int tag; double bytes; };
+  long long tag_launch[HB_N];
+  double tag_ms[HB_N], tag_bytes[HB_N];
   std::vector<ProfRec> prof;
   long long prof_launch[PROF_NCLS];
   double prof_ms[PROF_NCLS], prof_flops[PROF_NCLS];

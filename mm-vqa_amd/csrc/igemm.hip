@@ -1757,21 +1757,23 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     std::vector<Cand> cands;
     const int tiles_f[] = {1, 2, 3, 4, 5, 6}, tiles_w[] = {1, 2, 3, 4, 5, 6};
     static const bool persist_off = getenv("MMVQA_NO_PERSIST") != nullptr;   // A/B switch: no persistent candidates
+    // which products may take the persistent form: bit 0 forward / data gradient (caller's stream), bit 1 weight gradient
+    static const int persist_kinds = getenv("MMVQA_PERSIST_KINDS") ? atoi(getenv("MMVQA_PERSIST_KINDS")) : 3;
     if (kind == KIND_WGRAD && p.splitk <= 0) {
       for (int t : tiles_w) for (int sk : {0, 1, 2, 3, 4, 6, 8, 12, 16}) cands.push_back({t, sk, 0});
       // persistent form: an equal share of the K-tile iterations per workgroup, tiles accumulated with atomics as in any split
-      if (!persist_off && p.c_atomic && p.epi_mode == EPI_PLAIN)
+      if (!persist_off && (persist_kinds & 2) && p.c_atomic && p.epi_mode == EPI_PLAIN)
         for (int t : {3, 5, 6}) for (int g : {256, 512, 1024}) cands.push_back({t, 1, g});
     } else if (kind == KIND_WGRAD) {
       for (int t : tiles_w) cands.push_back({t, p.splitk, 0});
-    } else if (sk_eligible(p, kind) && p.splitk <= 0 && (long)cdiv(p.M, 64) * cdiv(p.N, 64) <= 224) {
+    } else if (sk_eligible(p, kind) && p.splitk <= 0 && (long)cdiv(p.M, 64) * cdiv(p.N, 64) <= 320) {
       // few output tiles: also try K split over workgroups with a finishing launch (needs the caller's scratch)
       for (int t : {3, 5, 6}) for (int sk : {1, 2, 3, 4, 6, 8}) cands.push_back({t, sk, 0});
       for (int t : {1, 2, 4}) cands.push_back({t, 1, 0});
     } else {
       for (int t : tiles_f) cands.push_back({t, p.splitk, 0});
     }
-    if (!persist_off && kind != KIND_WGRAD && sk_eligible(p, kind) && p.sk_cnt && p.splitk <= 0)
+    if (!persist_off && (persist_kinds & 1) && kind != KIND_WGRAD && sk_eligible(p, kind) && p.sk_cnt && p.splitk <= 0)
       for (int t : {3, 5, 6}) for (int g : {256, 512}) cands.push_back({t, 1, g});
     hipEvent_t e0, e1;
     HIP_CHECK_RET(hipEventCreate(&e0));

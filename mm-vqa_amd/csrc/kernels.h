@@ -15,6 +15,10 @@ struct IgemmTuner {
 void mmvqa_set_tuner(IgemmTuner* t);
 int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t stream);
 int mmvqa_launch_attention(const AttnParams& p, int head_dim, int bwd, hipStream_t st);
+// qkvattn.hip: fused QKV projection + self-attention of a BertLayer (forward), T <= 32, head dimension 64
+bool k_qkv_attn_fwd_ok(int T, int H, int heads);
+int k_qkv_attn_fwd(hipStream_t st, const float* xn, const float* W, const float* bias, const long long* mask, float* qkv,
+                   float* probs, float* ctx, int B, int T, int H, int heads, float drop_p, uint32_t seed);
 
 int k_bn_coef_fwd(hipStream_t st, const double* stat, int C, double count, float eps, const float* gamma,
                   const float* beta, float* run_mean, float* run_var, long long* nbt, float momentum, int reps,
@@ -97,6 +101,7 @@ int k_tap_thin_bwd(hipStream_t st, const float* x, const float* sc, const float*
 int k_skinny_fwd(hipStream_t st, const float* x, int x_ld, const float* W, const float* b, int act, float* pre,
                  float* y, int M, int N, int K);
 size_t k_se_fc_bwd_scratch_floats(int B, int mid, int rd);
+bool k_se_fc_bwd_ok(int rd);   // the backward kernels keep an rd-wide tile in LDS: widths beyond their limit are refused at plan time
 int k_se_fc_bwd(hipStream_t st, const float* dgate, const float* gpre, const float* r, const float* rpre,
                 const float* pool, const float* We, const float* Wr, float* dWe, float* dbe, float* dWr, float* dbr,
                 float* dpool, float* scratch, int scratch_is_zero, int B, int mid, int rd);

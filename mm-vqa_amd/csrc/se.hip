@@ -412,6 +412,8 @@ int k_skinny_fwd(hipStream_t st, const float* x, int x_ld, const float* W, const
   return MMVQA_OK;
 }
 
+bool k_se_fc_bwd_ok(int rd) { return rd > 0 && rd <= SE_MAXRD; }
+
 size_t k_se_fc_bwd_scratch_floats(int B, int mid, int rd) { (void)mid; return (size_t)B * rd; }
 
 // gradients of both squeeze-excite layers: accumulates dW_e, db_e, dW_r, db_r; writes dpool[B, mid].

@@ -423,22 +423,38 @@ class Model(nn.Module):
         L.check(L.lib().mmvqa_engine_profile(self._handle, (2 if serialized else 1) if enable else 0))
 
     REGIONS = ("backbone", "tap", "qkv", "attention", "encoder_rest", "heads", "embed", "bn_coef")
+    # igemm_kernel | attention kernels | launches without matrix work | matrix work outside igemm_kernel (tapthin.hip, se.hip)
+    PROFILE_CLASSES = ("igemm", "attention", "other", "matrix_other")
 
     def profile_read_regions(self):
         """{region: {class: {launches, ms, flops}}} of the profiled step (mmvqa_engine_profile_read_region)"""
         out = {}
         for r, rn in enumerate(self.REGIONS):
             out[rn] = {}
-            for cls, nm in enumerate(("igemm", "attention", "other")):
+            for cls, nm in enumerate(self.PROFILE_CLASSES):
                 n, ms, fl = C.c_longlong(), C.c_double(), C.c_double()
                 L.check(L.lib().mmvqa_engine_profile_read_region(self._handle, r, cls, C.byref(n), C.byref(ms),
                                                                  C.byref(fl)))
                 out[rn][nm] = dict(launches=n.value, ms=ms.value, flops=fl.value)
         return out
 
+    HBM_KERNELS = ("bn_add_relu", "maxpool_fwd", "maxpool_bwd", "layernorm_fwd", "layernorm_bwd", "dropout_copy", "bn_act_add",
+                   "dwconv_fwd", "dwconv_bwd_data", "dwconv_bwd_weight", "se_pool", "se_dgate", "act_bwd_stats",
+                   "tap_thin_fwd", "tap_thin_bwd")
+
+    def profile_read_hbm(self):
+        """{kernel: {launches, ms, bytes}} of the HBM-bound kernels of the profiled step (mmvqa_engine_profile_read_hbm)"""
+        out = {}
+        for k, nm in enumerate(self.HBM_KERNELS, start=1):
+            n, ms, by = C.c_longlong(), C.c_double(), C.c_double()
+            L.check(L.lib().mmvqa_engine_profile_read_hbm(self._handle, k, C.byref(n), C.byref(ms), C.byref(by)))
+            if n.value:
+                out[nm] = dict(launches=n.value, ms=ms.value, bytes=by.value)
+        return out
+
     def profile_read(self):
         out = {}
-        for cls, nm in enumerate(("igemm", "attention", "other")):
+        for cls, nm in enumerate(self.PROFILE_CLASSES):
             n, ms, fl = C.c_longlong(), C.c_double(), C.c_double()
             L.check(L.lib().mmvqa_engine_profile_read(self._handle, cls, C.byref(n), C.byref(ms), C.byref(fl)))
             out[nm] = dict(launches=n.value, ms=ms.value, flops=fl.value)

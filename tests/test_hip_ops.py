@@ -835,6 +835,57 @@ def test_attention_bert(B, T, heads, D):
     assert_close(dqkv, qkv.grad, TOL, "dqkv")
 
 
+@pytest.mark.parametrize("B,T,heads", [(16, 32, 12), (3, 28, 12), (2, 10, 2), (1, 1, 1)])
+def test_fused_qkv_projection_and_attention(B, T, heads):
+    """mmvqa_qkv_attention_fwd: proj_q / proj_k / proj_v + attention of a BertLayer in one launch
+    (models/transformer.py:19-30), ragged key masks, T < 32; q|k|v, probabilities and context against torch, and -- with
+    dropout -- against the two-launch path it replaces (same counter-based stream: bit-equal masks)."""
+    torch.manual_seed(31)
+    D = 64
+    H = heads * D
+    xn = torch.randn(B * T, H)
+    W = torch.randn(3 * H, H) / math.sqrt(H)
+    bias = torch.randn(3 * H) * 0.1
+    mask = torch.ones(B, T, dtype=torch.long)
+    for b in range(B):
+        mask[b, max(1, T - 2 * (b % 5) - 1):] = 0
+    qkv_ref = xn @ W.t() + bias
+    q, k, v = (qkv_ref[:, i * H:(i + 1) * H].view(B, T, heads, D).transpose(1, 2) for i in range(3))
+    sc = q @ k.transpose(-2, -1) / float(math.sqrt(D)) - 10000.0 * (1.0 - mask[:, None, None, :].float())
+    pr = F.softmax(sc, dim=-1)
+    ctx_ref = (pr @ v).transpose(1, 2).contiguous().view(B * T, H)
+    xd, Wd, bd, md = xn.to(dev()), W.to(dev()), bias.to(dev()), mask.to(dev())
+
+    def fused(drop_p, seed):
+        qkv = torch.full((B * T, 3 * H), float("nan"), device=dev())
+        probs = torch.zeros(B, heads, T, T, device=dev())
+        ctx = torch.full((B * T, H), float("nan"), device=dev())
+        L.check(L.lib().mmvqa_qkv_attention_fwd(L.stream_ptr(), P(xd), P(Wd), P(bd), P(md), P(qkv), P(probs), P(ctx), B, T, H,
+                                                heads, drop_p, seed))
+        torch.cuda.synchronize()
+        return qkv, probs, ctx
+
+    qkv, probs, ctx = fused(0.0, 0)
+    assert_close(qkv, qkv_ref, TOL, "q|k|v")
+    assert_close(probs.transpose(-1, -2), pr, TOL, "probs")
+    assert_close(ctx, ctx_ref, TOL, "ctx")
+    # dropout: the two-launch path (projection values from the fused run, so that only the attention differs)
+    qkv, probs, ctx = fused(0.3, 1234)
+    ctx2 = torch.zeros(B * T, H, device=dev())
+    probs2 = torch.zeros(B, heads, T, T, device=dev())
+    a = L.AttnDesc()
+    a.q, a.k, a.v = P(qkv), P(qkv) + 4 * H, P(qkv) + 8 * H
+    a.row_stride, a.head_stride = 3 * H, D
+    a.out, a.out_row_stride, a.out_head_stride = P(ctx2), H, D
+    a.mask, a.mask_on_query, a.probs = P(md), 0, P(probs2)
+    a.B, a.T, a.heads, a.sqrt_d, a.drop_p, a.seed = B, T, heads, math.sqrt(D), 0.3, 1234
+    L.check(L.lib().mmvqa_attention(C.byref(a), D, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert_close(probs, probs2, 1e-6, "probabilities, fused vs two launches")
+    assert_close(ctx, ctx2, 1e-5, "context with dropout, fused vs two launches")
+    assert relerr(ctx, ctx_ref) > 1e-2      # dropout really was applied
+
+
 @pytest.mark.parametrize("B,T,es", [(2, 32, 96), (3, 9, 12), (2, 40, 96)])
 def test_attention_realformer(B, T, es):
     """models/realformer.py:30-45: k,q,v split, residual scores, QUERY-axis mask, prev chain"""

@@ -50,8 +50,12 @@ def main():
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
     ap.add_argument("--nopro", action="store_true", help="plain operand loads (no BN prologue): prices the fused prologues")
     ap.add_argument("--nostat", action="store_true", help="forward without the statistics epilogue")
+    ap.add_argument("--persist", default="0", help="comma list of persistent-form workgroup counts to time beside 0 (= one workgroup per tile)")
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(",")]
+    persists = [int(t) for t in a.persist.split(",")]
+    ws = torch.zeros(8 << 20, device=dev())
+    tickets = torch.zeros(16384, dtype=torch.int32, device=dev())
     tot = {}
     print(f"{'shape':14s} {'kind':6s} tile {'M':>7s} {'N':>6s} {'K':>6s} {'us':>9s} {'TFLOP/s':>8s}")
     for name, N, H, W, Cin, Cout, K, s, p, cnt in SHAPES:
@@ -69,7 +73,10 @@ def main():
         stat = torch.zeros(16, Cout, 2, dtype=torch.float64, device=dev())
         flops = 2.0 * N * OH * OW * Cout * K * K * Cin
         for kind in a.kinds.split(","):
+          for persist in persists:
             for tile in tiles:
+                if persist and tile not in (3, 5, 6):
+                    continue
                 if kind == "fwd":
                     d, _, _ = conv_desc_fwd(x, w, N, H, W, Cin, Cout, K, s, p, z)
                     if not a.nopro:
@@ -92,9 +99,12 @@ def main():
                         L.check(L.lib().mmvqa_pixmask(L.stream_ptr(), P(tab), N, OH, OW, H, W, K, K, s, p))
                         d.pixmask = P(tab)
                     kd = L.KIND_WGRAD
+                if persist:
+                    d.persist, d.splitk = persist, 1
+                    d.sk_ws, d.sk_ws_floats, d.sk_cnt, d.sk_cnt_n = P(ws), ws.numel(), P(tickets), tickets.numel()
                 us = timeit(lambda: L.check(L.lib().mmvqa_igemm(C.byref(d), kd, 0, tile, L.stream_ptr())))
-                print(f"{name:14s} {kind:6s} {tile:4d} {d.M:7d} {d.N:6d} {d.K:6d} {us:9.1f} {flops / us / 1e6:8.1f}", flush=True)
-                if tile == tiles[0]:
+                print(f"{name:14s} {kind:6s} {tile:4d} {d.M:7d} {d.N:6d} {d.K:6d} {us:9.1f} {flops / us / 1e6:8.1f}" + (f"  persist {persist}" if persist else ""), flush=True)
+                if tile == tiles[0] and not persist:
                     tot[kind] = tot.get(kind, 0.0) + us * cnt
     print("weighted us per step (first tile option):", {k: round(v) for k, v in tot.items()}, "sum", round(sum(tot.values())))
 

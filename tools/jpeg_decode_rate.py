@@ -128,6 +128,8 @@ def main():
             res = dict(batch=B, mb=host.numel() / 1e6, ms_alone=ms, gbps_alone=gb / (ms * 1e-3), images_per_s_alone=B / (ms * 1e-3))
             # beside a compute stream that keeps the chip busy (a large fp32 matmul loop stands in for the training step)
             x = torch.randn(4096, 4096, device="cuda")
+            for _ in range(3):
+                y = x @ x            # (first call initialises the GEMM library)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(20):

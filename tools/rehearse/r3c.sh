@@ -1,5 +1,5 @@
 set -e -o pipefail
-cd "${GRAFT_REPO_ROOT:?}"
+cd "${GRAFT_STAGE:-${GRAFT_REPO_ROOT:?}}"
 mkdir -p gpurun_out/r3c
 timeout -k 10 900 python -m pytest tests -q -m gpu --durations=15 > gpurun_out/r3c/tests.log 2>&1 || { tail -40 gpurun_out/r3c/tests.log; exit 1; }
 tail -25 gpurun_out/r3c/tests.log

@@ -1,5 +1,5 @@
 set -o pipefail
-cd "${GRAFT_REPO_ROOT:?}"
+cd "${GRAFT_STAGE:-${GRAFT_REPO_ROOT:?}}"
 mkdir -p gpurun_out/r3d
 timeout -k 10 600 python -m pytest tests/test_hip_ops.py -q -m gpu --durations=5 -k "persistent or folded or conv_ or linear" > gpurun_out/r3d/ops.log 2>&1
 tail -15 gpurun_out/r3d/ops.log
