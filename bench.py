@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--nccl-algo", type=str, default=None, help="NCCL_ALGO for RCCL (e.g. Ring, Tree)")
     ap.add_argument("--nccl-proto", type=str, default=None, help="NCCL_PROTO (e.g. Simple, LL, LL128)")
     ap.add_argument("--nccl-min-nchannels", type=int, default=None, help="NCCL_MIN_NCHANNELS: more channels use more xGMI links at once")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="gradient all-reduce through include/mmvqa_comm.h (mmvqa_allreduce_bucket on an own RCCL communicator and "
+                         "stream) instead of torch.distributed.all_reduce")
     a = ap.parse_args()
     for k, v in (("NCCL_ALGO", a.nccl_algo), ("NCCL_PROTO", a.nccl_proto), ("NCCL_MIN_NCHANNELS", a.nccl_min_nchannels)):
         if v is not None:
@@ -209,7 +212,7 @@ def main():
 
     import mmvqa_amd
     from mmvqa_amd import synth
-    from mmvqa_amd.ddp import GradReducer, comm_info, sync_replicas
+    from mmvqa_amd.ddp import GradReducer, NativeComm, comm_info, sync_replicas
 
     torch.manual_seed(1234)            # identical initial weights on every rank
     torch.set_num_threads(min(host_cores(), 16))
@@ -220,7 +223,8 @@ def main():
     model.set_seed(1234 + rank)
     replica_checksum = sync_replicas(model)    # broadcast from rank 0 + checksum equal on every rank (raises otherwise)
     opt = mmvqa_amd.FusedAdam(model, lr=2e-5)
-    red = GradReducer(model.flat_grads, bucket_mb=a.bucket_mb)
+    native = NativeComm() if (a.native_comm and world > 1 and not rehearse) else None
+    red = GradReducer(model.flat_grads, bucket_mb=a.bucket_mb, native=native)
     if world > 1:
         # all-reduce of finished gradient ranges overlaps the backbone backward; `ready` orders RCCL's stream explicitly
         model.set_grad_ready_hook(red.start, with_event=True)
@@ -358,7 +362,7 @@ def main():
                config=dict(workload=wl + "; dropout on, train-mode BN; random-init weights",
                            global_batch=B_PER_GPU * world, seq_len=T, parallelism=f"dp{world}",
                            samples_per_s_per_gpu=value / world, final_loss=float(last.detach() if hasattr(last, "detach") else last),
-                           comm=dict(comm_info(red), replica_checksum=replica_checksum,
+                           comm=dict(comm_info(red), replica_checksum=replica_checksum, native_comm=native is not None,
                                      rehearsal_on_one_gpu=rehearse)))
     if roof is not None:
         out["roofline"] = roof

@@ -1758,7 +1758,7 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     const int tiles_f[] = {1, 2, 3, 4, 5, 6}, tiles_w[] = {1, 2, 3, 4, 5, 6};
     static const bool persist_off = getenv("MMVQA_NO_PERSIST") != nullptr;   // A/B switch: no persistent candidates
     // which products may take the persistent form: bit 0 forward / data gradient (caller's stream), bit 1 weight gradient
-    static const int persist_kinds = getenv("MMVQA_PERSIST_KINDS") ? atoi(getenv("MMVQA_PERSIST_KINDS")) : 3;
+    static const int persist_kinds = getenv("MMVQA_PERSIST_KINDS") ? atoi(getenv("MMVQA_PERSIST_KINDS")) : 0;
     if (kind == KIND_WGRAD && p.splitk <= 0) {
       for (int t : tiles_w) for (int sk : {0, 1, 2, 3, 4, 6, 8, 12, 16}) cands.push_back({t, sk, 0});
       // persistent form: an equal share of the K-tile iterations per workgroup, tiles accumulated with atomics as in any split

@@ -18,10 +18,86 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+class NativeComm:
+    """RCCL communicator behind the C ABI of include/mmvqa_comm.h (libmmvqa_comm.so): the `mmvqa_allreduce_bucket` /
+    `mmvqa_allgather` "thin wrappers over RCCL comms created by the Python launcher" of SURVEY.md 8(b).  Rank 0 draws the
+    rendezvous id; the other ranks get its bytes over torch.distributed (any backend); one communicator per process on
+    the current device.  Collectives are enqueued on the given (default: current) HIP stream and return at once."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            import ctypes as C
+            import os
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmmvqa_comm.so")
+            if not os.path.exists(path):
+                raise RuntimeError(f"{path} not found: build it with `make -C mm-vqa_amd/csrc` (needs RCCL)")
+            L = C.CDLL(path)
+            L.mmvqa_comm_last_error.restype = C.c_char_p
+            P, LL = C.c_void_p, C.c_longlong
+            for name, args in (("mmvqa_comm_unique_id", [P]), ("mmvqa_comm_create", [P, C.c_int, C.c_int, C.POINTER(P)]),
+                               ("mmvqa_comm_destroy", [P]), ("mmvqa_comm_rank", [P]), ("mmvqa_comm_world", [P]),
+                               ("mmvqa_comm_rccl_version", []), ("mmvqa_allreduce_bucket", [P, P, P, LL]),
+                               ("mmvqa_allgather", [P, P, P, P, LL]), ("mmvqa_broadcast", [P, P, P, LL, C.c_int])):
+                fn = getattr(L, name)
+                fn.restype, fn.argtypes = C.c_int, args
+            cls._lib = L
+        return cls._lib
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("mmvqa_comm: " + self.lib().mmvqa_comm_last_error().decode())
+
+    def __init__(self, rank=None, world_size=None):
+        import ctypes as C
+        L = self.lib()
+        self.rank = (dist.get_rank() if dist.is_initialized() else 0) if rank is None else rank
+        self.world = world() if world_size is None else world_size
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            self._check(L.mmvqa_comm_unique_id(ident))
+        if self.world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0)
+            ident = C.create_string_buffer(box[0], 128)
+        self._h = C.c_void_p()
+        self._check(L.mmvqa_comm_create(ident, self.rank, self.world, C.byref(self._h)))
+
+    @staticmethod
+    def _stream(stream):
+        return (stream or torch.cuda.current_stream()).cuda_stream
+
+    def allreduce(self, t, stream=None):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._check(self.lib().mmvqa_allreduce_bucket(self._h, self._stream(stream), t.data_ptr(), t.numel()))
+
+    def allgather(self, send, recv, stream=None):
+        assert recv.numel() == send.numel() * self.world and send.is_contiguous() and recv.is_contiguous()
+        self._check(self.lib().mmvqa_allgather(self._h, self._stream(stream), send.data_ptr(), recv.data_ptr(), send.numel()))
+
+    def broadcast(self, t, root=0, stream=None):
+        self._check(self.lib().mmvqa_broadcast(self._h, self._stream(stream), t.data_ptr(), t.numel(), root))
+
+    def rccl_version(self):
+        return self.lib().mmvqa_comm_rccl_version()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib().mmvqa_comm_destroy(self._h)
+            self._h = None
+
+
 class GradReducer:
-    def __init__(self, flat_grads: torch.Tensor, bucket_mb: float = 64.0):
+    def __init__(self, flat_grads: torch.Tensor, bucket_mb: float = 64.0, native: "NativeComm | None" = None):
+        """native: exchange the buckets through include/mmvqa_comm.h (`mmvqa_allreduce_bucket` on a communication stream
+        of its own) instead of torch.distributed's all_reduce"""
         self.flat = flat_grads
         self.bucket_mb = float(bucket_mb)
+        self.native = native
+        self.comm_stream = torch.cuda.Stream() if native is not None else None
+        self.native_pending = False
         n = flat_grads.numel()
         per = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets = []
@@ -44,9 +120,24 @@ class GradReducer:
         happens to be current when the callback fires (gloo synchronises on the host and hides a missing edge)."""
         if ready is not None:
             torch.cuda.current_stream().wait_event(ready)
-        if world() == 1:
+        if world() == 1 and self.native is None:
             return
         hi = self.flat.numel() if hi is None else hi
+        if self.native is not None:
+            # the communication stream is ordered behind the range's last writer (the ready event, or everything enqueued
+            # on the current stream so far) and runs beside the rest of the backward pass
+            ev = ready
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record()
+            self.comm_stream.wait_event(ev)
+            for a, b in self.buckets:
+                a2, b2 = max(a, lo), min(b, hi)
+                if a2 < b2:
+                    self.native.allreduce(self.flat[a2:b2], stream=self.comm_stream)
+            self.native_pending = True
+            self.launched += max(0, hi - lo)
+            return
         for a, b in self.buckets:
             a2, b2 = max(a, lo), min(b, hi)
             if a2 < b2:
@@ -55,10 +146,13 @@ class GradReducer:
 
     def finish(self):
         """all-reduce whatever backward did not announce (no hook installed), then wait for everything"""
-        if world() > 1 and self.launched == 0:
+        if (world() > 1 or self.native is not None) and self.launched == 0:
             self.start()
         for w in self.pending:
             w.wait()
+        if self.native_pending:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)   # Adam reads the reduced gradients
+            self.native_pending = False
         self.pending = []
         self.launched = 0
 

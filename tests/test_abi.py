@@ -137,3 +137,17 @@ def test_model_protocol_on_cpu():
     with pytest.raises(mmvqa_amd.MMVQAError):
         m(torch.zeros(1, 3, 32, 32), torch.zeros(1, 8, dtype=torch.long), torch.zeros(1, 8, dtype=torch.long),
           torch.ones(1, 8, dtype=torch.long))
+
+
+def test_comm_library_exports_every_declared_symbol():
+    """include/mmvqa_comm.h (the RCCL wrappers of SURVEY 8(b)): libmmvqa_comm.so loads and exports every entry point;
+    no collective is issued (no GPU here)"""
+    src = open(os.path.join(ROOT, "include", "mmvqa_comm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(mmvqa_\w+)\s*\(", src))
+    assert {"mmvqa_allreduce_bucket", "mmvqa_allgather", "mmvqa_broadcast", "mmvqa_comm_create", "mmvqa_comm_unique_id"} <= names
+    from mmvqa_amd.ddp import NativeComm
+    lib = NativeComm.lib()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mmvqa_comm.h but not exported"
+    assert lib.mmvqa_comm_rccl_version() > 20000

@@ -127,3 +127,34 @@ def test_two_rank_gathered_supcon_on_gpu():
     for rank, lerr, gerr in res:
         assert lerr <= 2e-5, f"rank {rank}: global SupCon loss differs from the oracle: {lerr:.2e}"
         assert gerr <= 1e-4, f"rank {rank}: feature gradient differs from the slice of the global one: {gerr:.2e}"
+
+
+def test_native_rccl_wrappers_on_a_one_rank_communicator():
+    """include/mmvqa_comm.h on the one GPU of the test box: a world-1 RCCL communicator (two ranks cannot share a device
+    under RCCL), all-reduce = identity, all-gather = copy, broadcast = no-op, all stream-ordered; and the GradReducer
+    route that bench.py --native-comm takes (buckets on the communication stream, joined before the optimizer)"""
+    import torch
+    from mmvqa_amd.ddp import GradReducer, NativeComm
+    dev = torch.device("cuda:0")
+    c = NativeComm(rank=0, world_size=1)
+    assert c.rccl_version() > 20000
+    g = torch.randn(100003, device=dev)
+    want = g.clone()
+    c.allreduce(g)
+    out = torch.zeros(4096, device=dev)
+    c.allgather(want[:4096].contiguous(), out)
+    c.broadcast(g)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want) and torch.equal(out, want[:4096])
+    red = GradReducer(g, bucket_mb=0.05, native=c)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g.mul_(2.0)                       # the "backward" producing the range on another stream
+        ev = torch.cuda.Event()
+        ev.record(s)
+    red.start(50000, None, ready=ev)      # tail first, ordered behind its writer by the event
+    red.start(0, 50000, ready=ev)
+    red.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(g, want * 2.0)
+    c.close()

@@ -51,6 +51,11 @@ def main():
             add("layer-3 3x3 convolutions (fwd + dgrad + wgrad)", busy, ns, fl)
         if M == 512 and N == 30522 or K == 30522 or M == 30522:
             add("vocabulary decoder GEMMs", busy, ns, fl)
+    # the fused QKV projection + attention launches of the forward pass (qkvattn.hip) are not igemm_kernel launches
+    for r in rows:
+        if "qkv_attn_fwd_kernel" in r["Kernel_Name"] and lo < int(r["Dispatch_Id"]) <= hi:
+            add("fused QKV projection + attention, forward (qkvattn.hip, 4 layers; B 16, T 32, 12 heads)", float(r["Counter_Value"]),
+                int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), 2.0 * 512 * 2304 * 768 + 4.0 * 16 * 12 * 32 * 32 * 64)
     res = {}
     for k, (n, busy, ns, fl) in groups.items():
         res[k] = dict(launches=n, mfma_busy_cycles=busy, kernel_ms=ns / 1e6, mfma_util=busy / (ns * CLK_GHZ * SIMDS),
