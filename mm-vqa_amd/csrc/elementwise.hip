@@ -1042,8 +1042,11 @@ int k_bn_add_relu_fold(hipStream_t st, const float* z, const mmvqa_bn_fold* f3, 
   if (C % 4 != 0 || !f3 || !f3->stat || f3->bwd || (fd && (!fd->stat || fd->bwd)))
     return mmvqa_set_error(MMVQA_ERR_ARG, "bn_add_relu_fold: C=%d must be a multiple of 4 and the folds forward ones", C);
   const int cb = cdiv_i(C, 64);
+  // rows per workgroup: every workgroup pays the fold of its 64 channels (~1.5 us of setup) before it streams its rows, so
+  // few, long workgroups; MMVQA_BAR_WGS = target number of workgroups (A/B)
+  static const long target = getenv("MMVQA_BAR_WGS") ? atol(getenv("MMVQA_BAR_WGS")) : 1024;
   int rpw = 32;
-  while ((long)cdiv_i(rows, rpw) * cb > 4096 && rpw < 256) rpw *= 2;
+  while ((long)cdiv_i(rows, rpw) * cb > target && rpw < 1024) rpw *= 2;
   mmvqa_bn_fold none;
   memset(&none, 0, sizeof(none));
   hipLaunchKernelGGL(bn_add_relu_fold_kernel, dim3(cdiv_i(rows, rpw), cb), dim3(256), 0, st, z, *f3, idn, fd ? *fd : none,
