@@ -120,21 +120,38 @@ def per_block(regs, marks, model, a):
         return sum(v["ms"] for v in regs[n].values())
 
     out = {}
-    out["qkv_gemm"] = gemm("qkv")                                  # fused QKV (or RealFormer kqv) fwd + dgrad + wgrad
-    at = regs["attention"]["attention"]
-    qk_ms = out["qkv_gemm"]["ms"] + at["ms"]
-    qk_fl = regs["qkv"]["igemm"]["flops"] + at["flops"]
+    out["qkv_gemm"] = gemm("qkv")                                  # fused QKV (or RealFormer kqv) GEMM launches: fwd (unless fused below) + dgrad + wgrad
+    at = regs["attention"]["attention"]                            # stand-alone attention launches (backward; forward unless fused)
+    fu = regs["qkv_attention_fused"]["attention"]                  # qkvattn.hip: projection + attention of a BertLayer, forward, one launch
+    if fu["launches"]:
+        tf_f = fu["flops"] / (fu["ms"] * 1e-3) / 1e12
+        out["qkv_attention_fused_fwd"] = dict(tflops=tf_f, frac_of_f32_mfma_peak=tf_f / PEAK_F32_MFMA_TFLOPS, ms=fu["ms"],
+                                              launches=fu["launches"], gflop=fu["flops"] / 1e9,
+                                              us_per_launch=fu["ms"] * 1e3 / fu["launches"])
+    qk_ms = out["qkv_gemm"]["ms"] + at["ms"] + fu["ms"]
+    qk_fl = regs["qkv"]["igemm"]["flops"] + at["flops"] + fu["flops"]
     tf = qk_fl / (qk_ms * 1e-3) / 1e12 if qk_ms > 0 else 0.0
+    fwd_ms = fu["ms"] if fu["launches"] else None
     out["qkv_plus_attention_block"] = dict(tflops=tf, frac_of_f32_mfma_peak=tf / PEAK_F32_MFMA_TFLOPS, ms=qk_ms,
                                            gflop=qk_fl / 1e9, target_frac=0.60,
-                                           note="north-star block: QKV projection GEMMs + attention kernels, fwd+bwd, 4 layers")
-    # attention softmax: algorithmic bytes per SURVEY 8(d) = read scores + write probs = 2*B*h*T^2*4 per layer forward
-    # (x3 for forward + backward: probs re-read, dscores written and read); the tensors are L2-resident at T=32
-    sm_bytes = 2.0 * B_PER_GPU * heads * T * T * 4 * L * 3
+                                           forward=dict(ms=fwd_ms, gflop=fu["flops"] / 1e9,
+                                                        frac_of_f32_mfma_peak=(fu["flops"] / (fu["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS))
+                                           if fu["launches"] else None,
+                                           backward=dict(ms=qk_ms - fu["ms"], gflop=(qk_fl - fu["flops"]) / 1e9,
+                                                         frac_of_f32_mfma_peak=((qk_fl - fu["flops"]) / ((qk_ms - fu["ms"]) * 1e-3) / 1e12
+                                                                                / PEAK_F32_MFMA_TFLOPS))
+                                           if fu["launches"] and qk_ms > fu["ms"] else None,
+                                           note="north-star block: QKV projection products + attention, fwd+bwd, 4 layers (forward = one "
+                                                "fused launch per layer when `forward` is set)")
+    # attention softmax: algorithmic bytes per SURVEY 8(d) = read scores + write probs = 2*B*h*T^2*4 per layer and pass; the
+    # stand-alone attention launches are forward + backward (x3) or, with the fused forward, backward only (x2); the
+    # tensors are L2-resident at T=32
+    passes = 2 if fu["launches"] else 3
+    sm_bytes = 2.0 * B_PER_GPU * heads * T * T * 4 * L * passes
     out["attention_softmax"] = dict(ms=at["ms"], launches=at["launches"], algorithmic_mb=sm_bytes / 1e6,
                                     gbps=sm_bytes / (at["ms"] * 1e-3) / 1e9 if at["ms"] > 0 else 0.0,
                                     frac_of_hbm_peak=(sm_bytes / (at["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if at["ms"] > 0 else 0.0,
-                                    note="score/prob tiles live in registers and L2 (T=32): latency-bound, not HBM-bound")
+                                    note="stand-alone attention launches only; score/prob tiles live in registers and L2 (T=32): latency-bound, not HBM-bound")
     out["backbone"] = dict(gemm("backbone", "tap"), total_ms_all_kernels=region_ms("backbone") + region_ms("tap") + region_ms("bn_coef"))
     out["taps"] = gemm("tap")
     out["encoder_rest"] = gemm("encoder_rest")

@@ -389,7 +389,8 @@ int mmvqa_engine_set_grad_callback(mmvqa_engine* e, mmvqa_grad_cb cb, void* user
 /* per-shape kernel configuration: while enabled, every implicit-GEMM shape met for the first time in
  * forward/backward is timed over its candidate (tile, split-K) set and the fastest is kept for later
  * calls.  A pass run with tuning enabled is a throw-away pass (outputs/statistics are garbage).
- * Returns the number of tuned shapes so far (>= 0) or a negative error. */
+ * Returns the number of tuned shapes so far (>= 0) or a negative error.  enable = 2 changes nothing and returns how many
+ * of the tuned shapes run in the persistent form (mmvqa_gemm_desc.persist). */
 int mmvqa_engine_tune(mmvqa_engine* e, int enable);
 /* per-kernel-class timing (HIP events on the launch stream) of the NEXT forward+backward:
  * enable, run, then read back {n_launches, total_ms, algorithmic_flops} per class.
@@ -400,7 +401,8 @@ int mmvqa_engine_profile_read(mmvqa_engine* e, int cls, long long* launches, dou
 /* the same split by region of the step (SURVEY 8(d) per-block figures): 0 CNN backbone, 1 tap 1x1 convs
  * (image_encoding.py:53-62), 2 fused QKV / kqv projection (transformer.py:13-20, realformer.py:32-33) fwd+dgrad+wgrad,
  * 3 attention core (transformer.py:22-27, realformer.py:34-44), 4 rest of the encoder, 5 heads (mmbert.py:133-137,
- * 154-166), 6 embeddings, 7 BatchNorm coefficient kernels */
+ * 154-166), 6 embeddings, 7 BatchNorm coefficient kernels, 8 the fused QKV projection + attention launch (class 1, its
+ * FLOPs = projection + attention) */
 int mmvqa_engine_profile_read_region(mmvqa_engine* e, int region, int cls, long long* launches, double* ms,
                                      double* flops);
 /* the HBM-bound kernels of the profiled step one by one: launches, total ms and ALGORITHMIC bytes (every tensor the

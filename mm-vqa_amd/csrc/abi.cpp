@@ -286,6 +286,11 @@ int mmvqa_engine_set_grad_callback(mmvqa_engine* e, mmvqa_grad_cb cb, void* user
 }
 int mmvqa_engine_tune(mmvqa_engine* e, int enable) {
   if (!e) return mmvqa_set_error(MMVQA_ERR_ARG, "tune: null engine");
+  if (enable == 2) {   // query: how many shapes run in the persistent form
+    int n = 0;
+    for (const auto& kv : e->tuner.table) n += kv.second.persist > 0;
+    return n;
+  }
   e->tuner.tuning = enable != 0;
   return (int)e->tuner.table.size();
 }

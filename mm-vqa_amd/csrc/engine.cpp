@@ -1321,9 +1321,9 @@ static int bert_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, cons
     TRY(ln_fwd(e, st, x, e->norm1, WS(L.xn1), WS(L.mean1), WS(L.rstd1), M, 1e-12f));
     static const bool fused_off = getenv("MMVQA_NO_FUSED_QKV") != nullptr;   // A/B switch
     if (!fused_off && k_qkv_attn_fwd_ok(e->T, H, d.heads)) {
-      // projection + attention of every (sample, head) in one launch (qkvattn.hip); its matrix work is booked under the
-      // attention region: the north-star block = QKV products + attention, whichever launch carries them
-      REG(REG_ATTN);
+      // projection + attention of every (sample, head) in one launch (qkvattn.hip): a profiler region of its own (the
+      // north-star block = QKV products + attention, whichever launches carry them: bench.py adds the three regions)
+      REG(REG_QKV_ATTN);
       RUN(PROF_ATTN, 2.0 * M * 3 * H * H + 4.0 * e->B * d.heads * (double)e->T * e->T * (H / d.heads),
           k_qkv_attn_fwd(st, WS(L.xn1), PRM(L.qkv.w), PRM(L.qkv.b), e->mask, WS(L.qkvo), WS(L.probs), WS(L.ctx), e->B, e->T,
                          H, d.heads, p, site_seed(e, i, 0)));

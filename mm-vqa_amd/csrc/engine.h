@@ -89,7 +89,7 @@ struct RFLayerRef {
 enum { PROF_IGEMM = 0, PROF_ATTN = 1, PROF_OTHER = 2, PROF_MATRIX = 3, PROF_NCLS = 4 };
 // profiler regions (per-block rooflines): which part of the step a launch belongs to
 enum { REG_BACKBONE = 0, REG_TAP = 1, REG_QKV = 2, REG_ATTN = 3, REG_ENC = 4, REG_HEAD = 5, REG_EMBED = 6,
-       REG_BNCOEF = 7, REG_N = 8 };
+       REG_BNCOEF = 7, REG_QKV_ATTN = 8 /* the fused projection + attention launch (qkvattn.hip) */, REG_N = 9 };
 
 // HBM-bound kernels the profiler reports one by one (algorithmic bytes / measured time against the 8 TB/s roofline)
 enum { HB_NONE = 0, HB_BN_ADD_RELU, HB_MAXPOOL_FWD, HB_MAXPOOL_BWD, HB_LAYERNORM_FWD, HB_LAYERNORM_BWD, HB_DROPOUT_COPY,

@@ -1809,8 +1809,9 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     std::vector<Cand> cands;
     const int tiles_f[] = {1, 2, 3, 4, 5, 6}, tiles_w[] = {1, 2, 3, 4, 5, 6};
     static const bool persist_off = getenv("MMVQA_NO_PERSIST") != nullptr;   // A/B switch: no persistent candidates
-    // which products may take the persistent form: bit 0 forward / data gradient (caller's stream), bit 1 weight gradient
-    static const int persist_kinds = getenv("MMVQA_PERSIST_KINDS") ? atoi(getenv("MMVQA_PERSIST_KINDS")) : 0;
+    // which products may take the persistent form: bit 0 forward / data gradient (caller's stream), bit 1 weight gradient;
+    // bit 2 (tests): a persistent candidate that ran wins its shape, so that a whole step runs in that form
+    const int persist_kinds = getenv("MMVQA_PERSIST_KINDS") ? atoi(getenv("MMVQA_PERSIST_KINDS")) : 0;   // (read per tuning pass: tests toggle it)
     if (kind == KIND_WGRAD && p.splitk <= 0) {
       for (int t : tiles_w) for (int sk : {0, 1, 2, 3, 4, 6, 8, 12, 16}) cands.push_back({t, sk, 0});
       // persistent form: an equal share of the K-tile iterations per workgroup, tiles accumulated with atomics as in any split
@@ -1845,8 +1846,9 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
       HIP_CHECK_RET(hipEventSynchronize(e1));
       float ms = 0.f;
       HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+      if (c.persist && (persist_kinds & 4)) ms *= 1e-3f;
       if (ms < best) { best = ms; bc = c; }
-      if (c.splitk <= 1 && ms < best_single) { best_single = ms; bc_single = c; }
+      if (c.splitk <= 1 && !c.persist && ms < best_single) { best_single = ms; bc_single = c; }
     }
     // K split with a finishing launch is timed here on an empty chip; inside the step it costs a second launch on the
     // dependency chain and takes the CUs the other stream would use: only worth it when clearly faster

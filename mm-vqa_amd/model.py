@@ -389,6 +389,10 @@ class Model(nn.Module):
         L.check(L.lib().mmvqa_engine_set_grad_callback(self._handle, C.cast(self._cb, C.c_void_p), None))
 
     # ------------------------------------------------------------------ per-shape kernel tuning
+    def tuned_persistent(self):
+        """how many of the tuned GEMM shapes run in the persistent (stream-K) form"""
+        return int(L.lib().mmvqa_engine_tune(self._handle, 2))
+
     def tune(self, img, input_ids, segment_ids, input_mask):
         """Time the candidate tile / split-K configurations of every GEMM shape of one training step
         (forward + backward on the given batch) and keep the fastest.  Parameters, BatchNorm buffers
@@ -422,7 +426,7 @@ class Model(nn.Module):
         """per-launch HIP-event timing of the next step; serialized=True puts every launch on one stream"""
         L.check(L.lib().mmvqa_engine_profile(self._handle, (2 if serialized else 1) if enable else 0))
 
-    REGIONS = ("backbone", "tap", "qkv", "attention", "encoder_rest", "heads", "embed", "bn_coef")
+    REGIONS = ("backbone", "tap", "qkv", "attention", "encoder_rest", "heads", "embed", "bn_coef", "qkv_attention_fused")
     # igemm_kernel | attention kernels | launches without matrix work | matrix work outside igemm_kernel (tapthin.hip, se.hip)
     PROFILE_CLASSES = ("igemm", "attention", "other", "matrix_other")
 

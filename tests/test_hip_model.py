@@ -92,7 +92,10 @@ def run_case(args, B, T, hw, kind, seed=0, stat_tol=1e-4, tune=False):
     """tune=True: the launcher's timed per-shape choices (tile, split-K, K split + finishing launch, persistent form) are
     made first -- Model.tune() on the case's own inputs, as bench.py and train.py do -- so that the kernels compared
     with the oracle are the ones the timed steps run.  tune="both": the default launch choices AND the tuned ones against
-    ONE evaluation of the CPU oracle (fp32 and fp64: the expensive part of a full-size case)."""
+    ONE evaluation of the CPU oracle (fp32 and fp64: the expensive part of a full-size case).  tune="all": a third model
+    whose tuning pass runs with MMVQA_PERSIST_KINDS=7 (bits 0/1 let the tuner try the persistent stream-K
+    form for forward / data-gradient and weight-gradient products, bit 2 makes it win wherever it runs), so that every
+    eligible product of the step -- both streams' ticketed fix-ups included -- runs in that form."""
     orc, hip = build_pair(args, seed)
     V = args.vocab_size
     if kind == "vqa":
@@ -109,16 +112,23 @@ def run_case(args, B, T, hw, kind, seed=0, stat_tol=1e-4, tune=False):
     oracle_loss(kind, orc64(img.double(), ids, seg, mask), tgt, B).backward()
     osd = orc.state_dict()
     dimg, dids, dseg, dmask, dtgt = (t.to(dev()) for t in (img, ids, seg, mask, tgt))
-    for tuned in ((False, True) if tune == "both" else (bool(tune),)):
+    for tuned in {"both": (False, True), "all": (False, True, "persist")}.get(tune, (bool(tune),)):
         if hip is None:
             hip = mmvqa_amd.Model(args)
             hip.load_state_dict(init_sd)
             hip.to(dev())
         hip.train()
-        if tuned:
+        if tuned == "persist":
+            os.environ["MMVQA_PERSIST_KINDS"] = "7"
+            try:
+                n = hip.tune(dimg, dids, dseg, dmask)
+            finally:
+                del os.environ["MMVQA_PERSIST_KINDS"]
+            assert hip.tuned_persistent() >= 20, (hip.tuned_persistent(), n)
+        elif tuned:
             n = hip.tune(dimg, dids, dseg, dmask)
-            assert n > 20, n
-        what = "tuned launches: " if tuned else ""
+            assert n > 20 and hip.tuned_persistent() == 0, (n, hip.tuned_persistent())
+        what = {False: "", True: "tuned launches: ", "persist": "persistent form: "}[tuned]
         out = hip(dimg, dids, dseg, dmask)
         if kind == "vqa":
             assert out[1] == 0 and out[2] == 0
@@ -207,9 +217,12 @@ def test_full_config2_batch16_the_bench_shape():
     """configs[1] exactly as bench.py runs it: per-GPU batch 16 (the tile / split-K choices and the grids differ from
     the batch-2 case above)"""
     # ... first with the launcher's default choices, then through the TUNED launcher (Model.tune(), as bench.py does):
-    # what bench.py times is what the oracle checks
+    # what bench.py times is what the oracle checks; then with every eligible product in the opt-in persistent form.
+    # (The persistent form is checked at THIS size on purpose: on a few-pixel mini network one ReLU within fp32 rounding
+    # of its kink moves a gradient by 1e-2 -- for the fp32 oracle against its own fp64 run just as for any kernel whose
+    # summation order differs -- and a different order flips different ones.)
     run_case(O.make_args(hidden_dropout_prob=0.0, emb_dropout_prob=0.0, rf_dropout_prob=0.0), B=16, T=32, hw=224,
-             kind="mlm", stat_tol=TOL, tune="both")
+             kind="mlm", stat_tol=TOL, tune="all")
 
 
 def test_full_config1_resnet152_transformer_vqa_head():
