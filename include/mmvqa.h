@@ -36,15 +36,6 @@ typedef void* mmvqa_stream_t; /* hipStream_t */
 
 #define MMVQA_STAT_SLOTS 16
 
-/* operand prologues of mmvqa_gemm_desc (a_pro / b_pro): applied while a tile is staged, per channel coefficients c0..c2 */
-#define MMVQA_PRO_NONE 0
-#define MMVQA_PRO_AFFINE_RELU 1 /* relu(A*c0 + c1): BatchNorm + ReLU of the producer (torchvision Bottleneck) */
-#define MMVQA_PRO_DZ 2          /* A*c0 + A2*c1 + c2: BatchNorm backward, dz = P*g + Q*z + R */
-#define MMVQA_PRO_AFFINE_SILU 4 /* silu(A*c0 + c1) (timm MBConv) */
-#define MMVQA_PRO_SILU_GATE 5   /* silu(A*c0 + c1) * gate[image][channel] (squeeze-excite) */
-#define MMVQA_PRO_BLOCK_END 6   /* relu(A*c0 + A2*c1 + c2): the end of the PREVIOUS Bottleneck, relu(bn3(z3) + [bn_d](identity)),
-                                   applied while conv1 of the next block loads its input (forward, 1x1 stride-1, uniform-tap loaders) */
-
 /* BatchNorm coefficients folded inside the CONSUMING launch (training mode).
  * The launches that produce a BatchNorm's input accumulate its per-channel sums into `stat`
  * ([MMVQA_STAT_SLOTS][C][2] doubles, the first `slots` replicas in use: forward sum z / sum z^2, backward
@@ -147,11 +138,6 @@ typedef struct mmvqa_gemm_desc {
   mmvqa_bn_fold a_fold; /* optional: the coefficients of the A prologue (a_pro AFFINE_RELU: scale/shift; DZ: P/Q/R) come
                            from raw sums instead of a_c0 / a_c1 / a_c2 (which may then be NULL) */
   int stat_slots;       /* replicas the statistics epilogue (stat1 / stat2) spreads its sums over; 0 = MMVQA_STAT_SLOTS */
-  mmvqa_bn_fold a_fold2; /* a_pro = 6 (block end on load) with a_fold: the BatchNorm of the SECOND tensor (the downsample branch);
-                            stat == NULL: the second tensor is added as it is */
-  float* A_out;         /* optional, forward, a_pro = 6: the tensor the A prologue produces is also WRITTEN here ([M][a_ld], the
-                           workgroups of column block 0 store the chunks they load) -- the block output torchvision's Bottleneck
-                           returns, materialised for the residual path and the backward pass without a launch of its own */
   int persist;          /* > 0: persistent ("stream-K") launch of that many workgroups, each walking an equal share of the
                            launch's K-tile iterations; tiles cut over several workgroups are completed by the workgroup
                            that arrives last.  Plain-epilogue products only; an accumulating product (c_atomic) needs

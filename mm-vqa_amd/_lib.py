@@ -17,7 +17,7 @@ c_ptr = C.c_void_p
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SERF, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 KIND_FWD, KIND_DGRAD, KIND_WGRAD = 0, 1, 2
-PRO_NONE, PRO_AFFINE_RELU, PRO_DZ, PRO_AFFINE, PRO_AFFINE_SILU, PRO_SILU_GATE, PRO_BLOCK_END = 0, 1, 2, 3, 4, 5, 6
+PRO_NONE, PRO_AFFINE_RELU, PRO_DZ, PRO_AFFINE, PRO_AFFINE_SILU, PRO_SILU_GATE = 0, 1, 2, 3, 4, 5
 EPI_PLAIN, EPI_TAP_FWD, EPI_TAP_BWD = 0, 1, 2
 STAT_SLOTS = 16
 
@@ -53,8 +53,7 @@ class GemmDesc(C.Structure):
         ("stat2", c_ptr), ("Z2", c_ptr), ("z2_ld", C.c_int), ("mean2", c_ptr), ("invstd2", c_ptr),
         ("colsum", c_ptr), ("gate", c_ptr), ("gate_hw", C.c_int), ("mk_mode", C.c_int), ("pixmask", c_ptr),
         ("sk_ws", c_ptr), ("sk_ws_floats", C.c_longlong),
-        ("a_fold", BnFold), ("stat_slots", C.c_int), ("a_fold2", BnFold), ("A_out", c_ptr), ("persist", C.c_int), ("sk_cnt", c_ptr),
-        ("sk_cnt_n", C.c_int),
+        ("a_fold", BnFold), ("stat_slots", C.c_int), ("persist", C.c_int), ("sk_cnt", c_ptr), ("sk_cnt_n", C.c_int),
         ("reserved0", C.c_int),
     ]
 

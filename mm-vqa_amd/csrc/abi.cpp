@@ -34,8 +34,8 @@ static int check_gemm(const mmvqa_gemm_desc* d, int kind, int nchw) {
     if (kind != KIND_FWD && (d->N & 3) && kind == KIND_DGRAD)
       return mmvqa_set_error(MMVQA_ERR_ARG, "igemm dgrad: N=%d must be a multiple of 4", d->N);
   }
-  if ((d->a_pro == PRO_DZ || d->a_pro == PRO_BLOCK_END) && (!d->A2 || (!d->a_fold.stat && (!d->a_c0 || !d->a_c1 || !d->a_c2))))
-    return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: a two-tensor prologue needs A2 and three coefficient arrays (or a_fold)");
+  if (d->a_pro == PRO_DZ && (!d->A2 || (!d->a_fold.stat && (!d->a_c0 || !d->a_c1 || !d->a_c2))))
+    return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: PRO_DZ needs A2 and three coefficient arrays (or a_fold)");
   if (d->g_SH <= 0 || d->g_SW <= 0 || d->g_OH <= 0 || d->g_OW <= 0 || d->g_Cs <= 0)
     return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: gather geometry not set");
   return MMVQA_OK;

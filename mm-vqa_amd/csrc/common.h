@@ -10,7 +10,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SERF = 3, ACT_SILU = 4, ACT_SIGMOID = 5 };
 // A/B operand prologues (applied when a tile is written to LDS)
-enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_DZ = 2, PRO_AFFINE = 3, PRO_AFFINE_SILU = 4, PRO_SILU_GATE = 5, PRO_BLOCK_END = 6 };
+enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_DZ = 2, PRO_AFFINE = 3, PRO_AFFINE_SILU = 4, PRO_SILU_GATE = 5 };
 // epilogue special modes
 enum { EPI_PLAIN = 0, EPI_TAP_FWD = 1, EPI_TAP_BWD = 2 };
 // contraction kinds of the implicit-GEMM family (MMVQA_KIND_* in the ABI)

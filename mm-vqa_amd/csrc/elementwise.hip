@@ -1044,7 +1044,7 @@ int k_bn_add_relu_fold(hipStream_t st, const float* z, const mmvqa_bn_fold* f3, 
   const int cb = cdiv_i(C, 64);
   // rows per workgroup: every workgroup pays the fold of its 64 channels (~1.5 us of setup) before it streams its rows, so
   // few, long workgroups; MMVQA_BAR_WGS = target number of workgroups (A/B)
-  static const long target = getenv("MMVQA_BAR_WGS") ? atol(getenv("MMVQA_BAR_WGS")) : 1024;
+  static const long target = getenv("MMVQA_BAR_WGS") ? atol(getenv("MMVQA_BAR_WGS")) : 4096;
   int rpw = 32;
   while ((long)cdiv_i(rows, rpw) * cb > target && rpw < 1024) rpw *= 2;
   mmvqa_bn_fold none;

@@ -646,40 +646,13 @@ static void set_fold_bwd(mmvqa_engine* e, mmvqa_bn_fold& f, const BNRef& bn, boo
   f.dgamma = GRD(bn.gamma); f.dbeta = GRD(bn.beta);
 }
 
-// The end of a Bottleneck, out = relu(bn3(z3) + [bn_d](identity)), that has not been applied yet: conv1 of the NEXT block
-// applies it while it loads its input and writes `out` on the way (igemm PRO_BLOCK_END + A_out) -- no launch of its own.
-struct PendingEnd {
-  bool on = false;
-  const float* z3 = nullptr; const float* idn = nullptr;
-  BNRef* b3 = nullptr; BNRef* bd = nullptr;
-  float* out = nullptr;
-  hipEvent_t ev_ds = nullptr;   // the downsample convolution of that block (side stream) must be complete
-  int tap = -1;                 // tap that reads `out` (the block ended a layer), or -1
-};
-
-// conv1 of a block can take over the previous block's end: training with folded BatchNorms, uniform-tap loaders
-// (channel count a multiple of the K-tile), coefficient table within the kernel's LDS budget
-// Measured time-neutral on config 2 (25.70 vs 25.71 ms per step, four alternating runs each: the two-tensor prologue and the
-// stores cost conv1 what the 45 removed launches saved), so it is OFF unless MMVQA_FUSED_BLOCK_END=1 (read per call: tests toggle it).
-static bool can_fuse_block_end(const mmvqa_engine* e, const BlockRef& next) {
-  const char* on = getenv("MMVQA_FUSED_BLOCK_END");
-  return on && on[0] == '1' && folding(e) && next.c1.Cin % 64 == 0 && 3 * next.c1.Cin <= 3072 && next.c1.KH == 1 && next.c1.stride == 1;
-}
-
 // z = conv(x) with x optionally = relu(bn_in(x_raw)); accumulates the batch statistics of z
 static int conv_fwd(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const float* x, const BNRef* bn_in, int N,
-                    int H, int W, int OH, int OW, float* z, BNRef& bn_out, const PendingEnd* pe = nullptr) {
+                    int H, int W, int OH, int OW, float* z, BNRef& bn_out) {
   GemmParams g;
   memset(&g, 0, sizeof(g));
   g.M = N * OH * OW; g.N = c.Cout; g.K = c.KH * c.KH * c.Cin;
   g.A = x; g.a_ld = c.Cin;
-  if (pe) {
-    // input = relu(bn3(z3) + [bn_d](idn)) of the previous block, formed on load and written to its `out`
-    g.A = pe->z3; g.A2 = pe->idn; g.a_pro = PRO_BLOCK_END; g.A_out = pe->out;
-    g.a_c0 = WS(pe->b3->scale); g.a_c1 = WS(pe->b3->shift); g.a_c2 = WS(pe->b3->shift);   // (placeholders: the fold supplies them)
-    set_fold_fwd(e, g.a_fold, *pe->b3);
-    if (pe->bd) set_fold_fwd(e, g.a_fold2, *pe->bd);
-  }
   if (bn_in) {
     g.a_pro = PRO_AFFINE_RELU; g.a_c0 = WS(bn_in->scale); g.a_c1 = WS(bn_in->shift);
     if (folding(e)) set_fold_fwd(e, g.a_fold, *const_cast<BNRef*>(bn_in));   // this launch is bn_in's first consumer
@@ -901,43 +874,18 @@ static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
                                    e->PW));
   const float* x = WS(e->p0);
   int layer = 0;
-  PendingEnd pend;
   for (size_t i = 0; i < e->blocks.size(); ++i) {
     BlockRef& b = e->blocks[i];
     hipEvent_t ev_ds = nullptr;
-    if (pend.on) {
-      // conv1 applies the previous block's end and materialises x (= its `out`); what else reads x starts after it
-      sc.need(pend.ev_ds);
-      TRY(conv_fwd(e, st, b.c1, x, nullptr, B, b.H, b.W, b.H, b.W, WS(b.z1), b.b1, &pend));
-      if (b.has_ds || pend.tap >= 0) sc.fork();
-      if (pend.tap >= 0) TRY(tap_fwd(e, sc.sd, pend.tap, x, nullptr));
-      if (b.has_ds) {
-        TRY(conv_fwd(e, sc.sd, b.cd, x, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.zd), b.bd));
-        ev_ds = sc.mark();
-      }
-      pend = PendingEnd();
-    } else {
-      if (b.has_ds) {
-        sc.fork();
-        TRY(conv_fwd(e, sc.sd, b.cd, x, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.zd), b.bd));
-        ev_ds = sc.mark();
-      }
-      TRY(conv_fwd(e, st, b.c1, x, nullptr, B, b.H, b.W, b.H, b.W, WS(b.z1), b.b1));
+    if (b.has_ds) {
+      sc.fork();
+      TRY(conv_fwd(e, sc.sd, b.cd, x, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.zd), b.bd));
+      ev_ds = sc.mark();
     }
+    TRY(conv_fwd(e, st, b.c1, x, nullptr, B, b.H, b.W, b.H, b.W, WS(b.z1), b.b1));
     TRY(conv_fwd(e, st, b.c2, WS(b.z1), &b.b1, B, b.H, b.W, b.OH, b.OW, WS(b.z2), b.b2));
     TRY(conv_fwd(e, st, b.c3, WS(b.z2), &b.b2, B, b.OH, b.OW, b.OH, b.OW, WS(b.z3), b.b3));
     const long rows = (long)B * b.OH * b.OW;
-    const bool ends_layer = (int)i == e->layer_end[layer];
-    if (i + 1 < e->blocks.size() && can_fuse_block_end(e, e->blocks[i + 1])) {
-      pend.on = true;
-      pend.z3 = WS(b.z3); pend.idn = b.has_ds ? WS(b.zd) : x;
-      pend.b3 = &b.b3; pend.bd = b.has_ds ? &b.bd : nullptr;
-      pend.out = WS(b.out); pend.ev_ds = ev_ds;
-      pend.tap = ends_layer ? 3 - layer : -1;
-      x = WS(b.out);
-      if (ends_layer) ++layer;
-      continue;
-    }
     if (folding(e)) {
       mmvqa_bn_fold f3, fd;
       set_fold_fwd(e, f3, b.b3);
@@ -953,7 +901,7 @@ static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
                                        WS(b.out), rows, b.c3.Cout));
     }
     x = WS(b.out);
-    if (ends_layer) {
+    if ((int)i == e->layer_end[layer]) {
       sc.fork();
       TRY(tap_fwd(e, sc.sd, 3 - layer, x, nullptr));
       ++layer;

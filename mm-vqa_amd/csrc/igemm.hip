@@ -49,8 +49,9 @@ struct GemmAux {
   int sk_slots;        // partial tiles a tile can receive (most contributors of one tile)
   float* sk_part;      // [tile][sk_slots][BM*BN]
   unsigned* sk_cnt;    // [tile] arrival tickets, zero before and after every launch
-  int out_mask;  // block-end prologue with A_out: K-tile t of a row panel is written by the workgroup of column block
-                 // (t & out_mask) -- the panel's column blocks share the stores; -1: column block 0 writes everything
+  int tick;            // split-K over the grid's z WITHOUT a finishing launch: the sk_slots (= splits) workgroups of a tile
+                       // publish their partial tiles to sk_part and draw tickets exactly as above; the last one sums and
+                       // runs the epilogue
   int xcd;       // workgroup ids are dealt round-robin to the 8 XCDs: renumber so that an XCD gets a CONTIGUOUS run of
                  // tiles (1: the N-tiles of an M-panel, 2: the M-tiles of an N-panel share that XCD's L2 instead of
                  // pulling the panel into up to 8 of them)
@@ -75,7 +76,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 #define MAX_TAPS 32
 #define SC1_AUX 16       // cache-policy bits of the raw buffer builtins on gfx950: 1 = sc0, 2 = nt, 16 = sc1 (write-through / L1 bypass)
-#define SK_PART_MAX 6    // most contributors of one tile in the persistent form (host-checked)
+#define SK_PART_MAX 8    // most contributors of one tile in the persistent form (host-checked)
 #define TRY_RET(x) do { int r_ = (x); if (r_ != MMVQA_OK) return r_; } while (0)
 
 // Phase timestamps of every workgroup (tools/igemm_trace.py builds the library with -DIGEMM_TRACE):
@@ -415,18 +416,6 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     const BnFold& f = p.a_fold;
     const bool pub = f.publish && (persistent ? (sk_Lg == 0 && sk_first) : (bx == 0 && by == 0 && bz == 0));
     if constexpr (A_ROWK) {
-      if (p.a_pro == PRO_BLOCK_END) {
-        // relu(bn3(A) + bn_d(A2)): c0 = scale3, c1 = scale_d (1 without a downsample BatchNorm), c2 = shift3 + shift_d
-        const BnFold& fd = p.a_fold2;
-        for (int c = tid; c < fold_C; c += NT) {
-          float s3, b3, sd = 1.f, bd = 0.f;
-          bn_fold_fwd(f, fold_C, c, pub, s3, b3);
-          if (fd.stat) bn_fold_fwd(fd, fold_C, c, pub && fd.publish, sd, bd);
-          ctab[c] = s3; ctab[fold_C + c] = sd; ctab[2 * fold_C + c] = b3 + bd;
-        }
-        if (pub && tid == 0 && f.nbt) *f.nbt += f.reps;
-        if (pub && tid == 64 && fd.stat && fd.publish && fd.nbt) *fd.nbt += fd.reps;
-      } else {
       for (int c = tid; c < fold_C; c += NT) {
         float k0, k1, k2 = 0.f;
         if (f.bwd) bn_fold_bwd(f, fold_C, c, pub, k0, k1, k2); else bn_fold_fwd(f, fold_C, c, pub, k0, k1);
@@ -434,7 +423,6 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
         if (f.bwd) ctab[2 * fold_C + c] = k2;
       }
       if (pub && tid == 0 && !f.bwd && f.nbt) *f.nbt += f.reps;
-      }
     } else {
       if (tid < BM) {
         const int c = lm0 + tid;
@@ -586,7 +574,6 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     f32x4 ac0, ac1, ac2;      // A-prologue coefficients of this tile's channels
     int tm[NAC];              // fast loaders: all-ones / zero halo mask of chunk r at this tile's tap
     int pm[NBC], tmb[NBC];    // weight gradient of a 3x3: tap-validity words of the stage's NEXT tile / B mask of this tile
-    int sA;                   // block-end prologue: the tile's byte offset in A (= in A_out)
   };
 
   f32x16 acc[TM][TN];
@@ -608,8 +595,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     constexpr int BPRO = decltype(BPRO_T)::value;
     constexpr int FAST = decltype(FAST_T)::value;
     constexpr bool LDSC = decltype(LDSC_T)::value;   // K-loop coefficient reads from the LDS table (uniform-tap loaders only)
-    constexpr bool A_TWO = (APRO == PRO_DZ || APRO == PRO_BLOCK_END);
-    constexpr bool A_C3 = A_TWO;                     // three coefficient arrays
+    constexpr bool A_TWO = (APRO == PRO_DZ);
     constexpr bool A_AFF = (APRO == PRO_AFFINE_RELU || APRO == PRO_AFFINE_SILU || APRO == PRO_SILU_GATE);
     constexpr bool B_AFF = (BPRO == PRO_AFFINE_RELU || BPRO == PRO_AFFINE_SILU || BPRO == PRO_SILU_GATE);
 
@@ -802,7 +788,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     // instruction's soffset.  Rows / columns outside the matrix and halo taps use an offset beyond
     // num_records: the hardware range check returns zeros without touching memory.
     constexpr int BIG = (int)0x80000000;
-    __amdgpu_buffer_rsrc_t rA, rA2, rB, rC0, rC1, rC2, rT, rOut;
+    __amdgpu_buffer_rsrc_t rA, rA2, rB, rC0, rC1, rC2, rT;
     int f_voffA[NAC], f_voffB[NBC], f_voffT[NBC], f_veB[NBC];
     int f_runT = 0, f_tapw = 0;                   // weight gradient of a 3x3: pixel-table offset, the workgroup's tap
     const int f_voffC = a_kq * 4;
@@ -821,11 +807,6 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
         const int shift = (KIND == KIND_FWD) ? (p.g_pad * p.g_SW + p.g_pad) * p.a_ld : f_maxneg;
         rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A - shift), 0, NREC, FLAGS);
         rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)((A_TWO ? p.A2 : p.A) - shift), 0, NREC, FLAGS);
-        // block end on load: the workgroups of a row panel also WRITE what the prologue produces, each the K-tiles
-        // (= channel blocks) that fall to its column block; a store that is not this workgroup's gets an offset beyond the
-        // window and fails the range check: no branch in the loop
-        if constexpr (APRO == PRO_BLOCK_END)
-          rOut = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A_out ? p.A_out : p.C), 0, (p.A_out && (x.out_mask >= 0 || bx == 0)) ? NREC : 0, FLAGS);
         const int vshift = (KIND == KIND_FWD) ? shift : 0;
 #pragma unroll
         for (int r = 0; r < NAC; ++r) {
@@ -835,7 +816,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
         if constexpr ((A_AFF || A_TWO) && !LDSC) {
           rC0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_c0, 0, p.g_Cs * 4, FLAGS);
           rC1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a_c1, 0, p.g_Cs * 4, FLAGS);
-          rC2 = __builtin_amdgcn_make_buffer_rsrc((void*)(A_C3 ? p.a_c2 : p.a_c1), 0, p.g_Cs * 4, FLAGS);
+          rC2 = __builtin_amdgcn_make_buffer_rsrc((void*)(APRO == PRO_DZ ? p.a_c2 : p.a_c1), 0, p.g_Cs * 4, FLAGS);
         }
         if (k_begin != 0) {
           if (taps > 1) { f_tap = k_begin / p.g_Cs; f_c = k_begin - f_tap * p.g_Cs; } else { f_tap = 0; f_c = k_begin; }
@@ -921,13 +902,11 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
         if constexpr ((A_AFF || A_TWO) && LDSC) {
           const float* cp = ctab + f_c + a_kq;          // f_c < g_Cs always: in range also for tiles past the end
           S.ac0 = *reinterpret_cast<const f32x4*>(cp); S.ac1 = *reinterpret_cast<const f32x4*>(cp + fold_C);
-          if constexpr (A_C3) S.ac2 = *reinterpret_cast<const f32x4*>(cp + 2 * fold_C);
+          if constexpr (APRO == PRO_DZ) S.ac2 = *reinterpret_cast<const f32x4*>(cp + 2 * fold_C);
         } else if constexpr (A_AFF || A_TWO) {
           S.ac0 = bload(rC0, f_voffC, f_sC); S.ac1 = bload(rC1, f_voffC, f_sC);
-          if constexpr (A_C3) S.ac2 = bload(rC2, f_voffC, f_sC);
+          if constexpr (APRO == PRO_DZ) S.ac2 = bload(rC2, f_voffC, f_sC);
         }
-        // where this tile's prologue result goes in A_out -- if this workgroup is the one that writes this K-tile
-        if constexpr (APRO == PRO_BLOCK_END) S.sA = (x.out_mask < 0 || ((f_c / BK) & x.out_mask) == bx) ? f_sA : BIG;
       } else {
         f_sA = f_runA; f_sB = f_runB;
       }
@@ -978,14 +957,6 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
           } else {
             v[0] = fmaxf(lo[0], 0.f); v[1] = fmaxf(lo[1], 0.f); v[2] = fmaxf(hi[0], 0.f); v[3] = fmaxf(hi[1], 0.f);
           }
-        } else if constexpr (APRO == PRO_BLOCK_END) {
-          // relu(bn3(z3) + [bn_d](identity)) of the previous block: z3 * c0 + idn * c1 + c2, clamped, kept in memory too
-          const f32x4 z = S.ra2[r];
-          f32x2 lo = __builtin_elementwise_fma(z.xy, S.ac1.xy, S.ac2.xy), hi = __builtin_elementwise_fma(z.zw, S.ac1.zw, S.ac2.zw);
-          lo = __builtin_elementwise_fma(v.xy, S.ac0.xy, lo); hi = __builtin_elementwise_fma(v.zw, S.ac0.zw, hi);
-          v[0] = fmaxf(lo[0], 0.f); v[1] = fmaxf(lo[1], 0.f); v[2] = fmaxf(hi[0], 0.f); v[3] = fmaxf(hi[1], 0.f);
-          typedef int i32x4 __attribute__((ext_vector_type(4)));
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rOut, f_voffA[r], S.sA, 0);
         } else if constexpr (APRO == PRO_DZ) {
           const f32x4 z = S.ra2[r];
           f32x2 lo = __builtin_elementwise_fma(z.xy, S.ac1.xy, S.ac2.xy), hi = __builtin_elementwise_fma(z.zw, S.ac1.zw, S.ac2.zw);
@@ -1160,7 +1131,7 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
 #ifndef EXP_NOSTORE
 #ifdef IGEMM_TRACE
           if constexpr (sl == SVX && FAST != 0) {   // time the wait for the whole stage that is about to be written to LDS
-            constexpr int NLD = (A_ROWK && (A_AFF || A_TWO) ? (A_C3 ? 3 : 2) : 0) + NAC * (A_TWO ? 2 : 1) + NBC;
+            constexpr int NLD = (A_ROWK && (A_AFF || A_TWO) ? (APRO == PRO_DZ ? 3 : 2) : 0) + NAC * (A_TWO ? 2 : 1) + NBC;
             const unsigned long long ta = __builtin_readcyclecounter();
             __builtin_amdgcn_s_waitcnt(0x0F70 | (NLD & 15) | ((NLD >> 4) << 14));   // vmcnt(NLD): this body's own loads stay in flight
             const unsigned long long tb = __builtin_readcyclecounter();
@@ -1244,7 +1215,6 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     using I2 = std::integral_constant<int, PRO_DZ>;
     using I4 = std::integral_constant<int, PRO_AFFINE_SILU>;
     using I5 = std::integral_constant<int, PRO_SILU_GATE>;
-    using I6 = std::integral_constant<int, PRO_BLOCK_END>;
     using G = std::integral_constant<int, 0>;    // general loaders
     using F1 = std::integral_constant<int, 1>;   // uniform-tap loaders
     using F2 = std::integral_constant<int, 2>;   // uniform-tap loaders + halo mask
@@ -1255,7 +1225,6 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     } else if constexpr (KIND == KIND_FWD) {
       if (x.fast == 1) {
         if (p.a_pro == PRO_AFFINE_RELU) { if (x.ldsc) run(I1{}, I0{}, F1{}, L1{}); else run(I1{}, I0{}, F1{}, L0{}); }
-        else if (p.a_pro == PRO_BLOCK_END) { if (x.ldsc) run(I6{}, I0{}, F1{}, L1{}); else run(I6{}, I0{}, F1{}, L0{}); }
         else run(I0{}, I0{}, F1{}, L0{});
       } else if (x.fast == 2) {
         if (p.a_pro == PRO_AFFINE_RELU) { if (x.ldsc) run(I1{}, I0{}, F2{}, L1{}); else run(I1{}, I0{}, F2{}, L0{}); }
@@ -1367,17 +1336,24 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
     }
   };
 
-  if (persistent && !p.c_atomic && (sk_k0 != 0 || sk_k1 != nkt_total)) {
-    // This segment covers only a part of its tile's K range.  Every contributor publishes its partial tile (write-through
-    // stores, MI355X_MICROARCH "Valid forms": all stores of the handed-off bytes sc1, every storing wave drains them, a
-    // workgroup barrier, then ONE lane's agent-scope atomic) and draws a ticket; the contributor whose ticket is the
-    // last adds the other partial tiles (sc1 loads) to its own and runs the epilogue.  Nobody waits for anybody.
-    const unsigned long long G = (unsigned long long)x.sk_G;
-    const unsigned long long i0 = (unsigned long long)sk_tile * nkt_total, i1 = i0 + nkt_total - 1;
-    const int w_first = (int)(((i0 + 1) * G - 1) / sk_T), w_last = (int)(((i1 + 1) * G - 1) / sk_T);
-    const int n_contrib = w_last - w_first + 1, my = (int)sk_Lg - w_first;
+  if (persistent ? (!p.c_atomic && (sk_k0 != 0 || sk_k1 != nkt_total)) : (x.tick != 0)) {
+    // This workgroup covers only a part of its tile's K range (a cut segment of the persistent form, or one split of a
+    // ticketed split-K grid).  Every contributor publishes its partial tile (write-through stores, MI355X_MICROARCH
+    // "Valid forms": all stores of the handed-off bytes sc1, every storing wave drains them, a workgroup barrier, then
+    // ONE lane's agent-scope atomic) and draws a ticket; the contributor whose ticket is the last sums the partial
+    // tiles (sc1 loads; always in slot order, so the result does not depend on who came last) and runs the epilogue.
+    // Nobody waits for anybody.
+    int n_contrib, my, tile_id;
+    if (persistent) {
+      const unsigned long long G = (unsigned long long)x.sk_G;
+      const unsigned long long i0 = (unsigned long long)sk_tile * nkt_total, i1 = i0 + nkt_total - 1;
+      const int w_first = (int)(((i0 + 1) * G - 1) / sk_T), w_last = (int)(((i1 + 1) * G - 1) / sk_T);
+      n_contrib = w_last - w_first + 1; my = (int)sk_Lg - w_first; tile_id = sk_tile;
+    } else {
+      n_contrib = x.sk_slots; my = bz; tile_id = by * x.sk_gx + bx;
+    }
     constexpr int Q = BM * BN / 4;   // float4 of a tile
-    __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(x.sk_part + (size_t)sk_tile * x.sk_slots * (BM * BN)), 0,
+    __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(x.sk_part + (size_t)tile_id * x.sk_slots * (BM * BN)), 0,
                                                                   x.sk_slots * BM * BN * 4, 0x00020000);
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     for (int i = tid; i < Q; i += NT) {
@@ -1385,16 +1361,20 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
       const f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[r * LDC + c * 4]);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rP, (my * Q + i) * 16, 0, SC1_AUX);
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's partial stores have left
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have left
     __syncthreads();
     if (tid == 0) {
-      const unsigned old = atomicAdd(&x.sk_cnt[sk_tile], 1u);
+      const unsigned old = atomicAdd(&x.sk_cnt[tile_id], 1u);
       const int last = old == (unsigned)(n_contrib - 1);
-      if (last) atomicExch(&x.sk_cnt[sk_tile], 0u);   // tickets are zero again for the next launch
+      if (last) atomicExch(&x.sk_cnt[tile_id], 0u);   // tickets are zero again for the next launch
       sk_last = last;
     }
     __syncthreads();
-    if (!sk_last) continue;
+    if (!sk_last) {
+      TRACE_MARK(4);
+      if (persistent) continue;
+      return;
+    }
     for (int i = tid; i < Q; i += NT) {
       const int r = i / (BN / 4), c = i - r * (BN / 4);
       f32x4 t[SK_PART_MAX];
@@ -1404,9 +1384,10 @@ __global__ __launch_bounds__(256 * KS, 2) void igemm_kernel(const GemmParams p, 
         if (q < n_contrib && q != my)
           t[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rP, (q * Q + i) * 16, 0, SC1_AUX));
       }
-      f32x4 v = *reinterpret_cast<const f32x4*>(&ctile[r * LDC + c * 4]);
+      const f32x4 own = *reinterpret_cast<const f32x4*>(&ctile[r * LDC + c * 4]);
+      f32x4 v = {0, 0, 0, 0};
 #pragma unroll
-      for (int q = 0; q < SK_PART_MAX; ++q) v += t[q];
+      for (int q = 0; q < SK_PART_MAX; ++q) v += (q == my) ? own : t[q];
       *reinterpret_cast<f32x4*>(&ctile[r * LDC + c * 4]) = v;
     }
     __syncthreads();
@@ -1598,8 +1579,7 @@ static int launch_cfg(GemmParams p, hipStream_t stream) {
     const int taps = p.g_KH * p.g_KW;
     const double lim = 2147483648.0 - 16777216.0;
     if (KIND != KIND_WGRAD) {
-      const bool pro_ok = (KIND == KIND_FWD) ? (p.a_pro == PRO_NONE || p.a_pro == PRO_AFFINE_RELU ||
-                                                (p.a_pro == PRO_BLOCK_END && taps == 1 && p.g_stride == 1 && p.g_pad == 0))
+      const bool pro_ok = (KIND == KIND_FWD) ? (p.a_pro == PRO_NONE || p.a_pro == PRO_AFFINE_RELU)
                                              : (p.a_pro == PRO_NONE || p.a_pro == PRO_DZ);
       const double a_bytes = (KIND == KIND_FWD) ? (double)p.M * p.g_stride * p.g_stride * p.a_ld * 4.0 + (double)(p.g_SW + 2) * p.g_KH * p.a_ld * 4.0
                                                 : (double)p.M * p.a_ld * 4.0;
@@ -1620,30 +1600,21 @@ static int launch_cfg(GemmParams p, hipStream_t stream) {
         x.fast = 2;
     }
   }
-  if (p.a_pro == PRO_BLOCK_END && !(KIND == KIND_FWD && x.fast == 1))
-    return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: the block-end prologue (a_pro 6) is for forward 1x1 stride-1 products on the uniform-tap loaders "
-                           "(K and g_Cs multiples of the K-tile)");
   // BatchNorm coefficients of the A prologue folded in the kernel's setup (mmvqa_bn_fold).  The K loop reads the LDS table
   // only in its uniform-tap forms; the weight gradient keeps its (loop-invariant) coefficients in registers.  Anything
   // else -- general loaders, a table beyond FOLD_MAX_FLOATS -- gets the coefficient launch in front, as before.
   x.ldsc = 0;
-  {
-    const int gx = (p.N + BN - 1) / BN;
-    x.out_mask = (gx & (gx - 1)) == 0 ? gx - 1 : -1;
-  }
   size_t fold_floats = 0;
   if (p.a_fold.stat) {
-    const int ncoef = (p.a_fold.bwd || p.a_pro == PRO_BLOCK_END) ? 3 : 2;
+    const int ncoef = p.a_fold.bwd ? 3 : 2;
     const size_t need = A_ROWK ? (size_t)ncoef * p.g_Cs : (size_t)3 * BM;
-    const bool pro_ok = p.a_fold.bwd ? p.a_pro == PRO_DZ : (p.a_pro == PRO_AFFINE_RELU || (p.a_pro == PRO_BLOCK_END && KIND == KIND_FWD));
+    const bool pro_ok = p.a_fold.bwd ? p.a_pro == PRO_DZ : p.a_pro == PRO_AFFINE_RELU;
     if (pro_ok && need <= FOLD_MAX_FLOATS && (KIND == KIND_WGRAD || x.fast != 0)) {
       x.ldsc = 1;
       fold_floats = need;
     } else {
       const BnFold f = p.a_fold;
       const int C = A_ROWK ? p.g_Cs : p.M;
-      if (p.a_pro == PRO_BLOCK_END)
-        return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: the block-end prologue with folded BatchNorms needs the uniform-tap loaders and at most %d channels", FOLD_MAX_FLOATS / 3);
       if (!f.publish || !f.out0 || !f.out1 || !f.out2)
         return mmvqa_set_error(MMVQA_ERR_ARG, "igemm: this launch cannot fold its BatchNorm coefficients in the kernel and has nowhere to publish them");
       if (f.bwd)
@@ -1658,8 +1629,17 @@ static int launch_cfg(GemmParams p, hipStream_t stream) {
   const size_t smem = ((tile_floats + fold_floats > epi_floats ? tile_floats + fold_floats : epi_floats)) * sizeof(float);
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splitk);
   // persistent ("stream-K") form
-  x.sk_G = 0; x.sk_gx = (int)grid.x; x.sk_gy = (int)grid.y; x.sk_slots = 0; x.sk_part = nullptr; x.sk_cnt = nullptr;
-  if (p.persist > 0 && !NCHW && BM == 64 && BN == 64 && p.epi_mode == EPI_PLAIN && !x.part && p.splitk == 1 && !p.A_out) {
+  x.sk_G = 0; x.sk_gx = (int)grid.x; x.sk_gy = (int)grid.y; x.sk_slots = 0; x.sk_part = nullptr; x.sk_cnt = nullptr; x.tick = 0;
+  // split-K of a forward / data-gradient product: with the caller's tickets the last workgroup of a tile finishes it
+  // (no second launch); MMVQA_SK_FINISH=1 keeps the finishing launch (A/B switch)
+  static const bool finish_form = getenv("MMVQA_SK_FINISH") != nullptr;
+  if (x.part && !finish_form && p.sk_cnt && p.splitk <= SK_PART_MAX && p.epi_mode == EPI_PLAIN) {
+    const long long tiles = (long long)grid.x * grid.y;
+    if (tiles <= p.sk_cnt_n && tiles * p.splitk * (long long)(BM * BN) <= p.sk_ws_floats) {
+      x.tick = 1; x.part = nullptr; x.sk_slots = p.splitk; x.sk_part = p.sk_ws; x.sk_cnt = p.sk_cnt;
+    }
+  }
+  if (p.persist > 0 && !NCHW && BM == 64 && BN == 64 && p.epi_mode == EPI_PLAIN && !x.part && p.splitk == 1) {
     const long long tiles = (long long)grid.x * grid.y, nkt = (p.K + BK - 1) / BK, T = tiles * nkt;
     long long G = p.persist < T ? p.persist : T;
     bool ok = G >= 8;
@@ -1685,8 +1665,8 @@ static int launch_cfg(GemmParams p, hipStream_t stream) {
     if (x.sk_G && !x.xcd) x.xcd = 1;
   }
   if (getenv("MMVQA_IGEMM_LOG"))   // one line per launch: which loader family a shape gets (diagnostics)
-    fprintf(stderr, "igemm kind %d fast %d tile %dx%dx%d ks %d M %d N %d K %d Cs %d taps %d stride %d apro %d bpro %d splitk %d persist %d fold %d\n", KIND, x.fast,
-            BM, BN, BK, KS, p.M, p.N, p.K, p.g_Cs, p.g_KH * p.g_KW, p.g_stride, p.a_pro, p.b_pro, p.splitk, x.sk_G, x.ldsc);
+    fprintf(stderr, "igemm kind %d fast %d tile %dx%dx%d ks %d M %d N %d K %d Cs %d taps %d stride %d apro %d bpro %d splitk %d persist %d fold %d tick %d\n", KIND, x.fast,
+            BM, BN, BK, KS, p.M, p.N, p.K, p.g_Cs, p.g_KH * p.g_KW, p.g_stride, p.a_pro, p.b_pro, p.splitk, x.sk_G, x.ldsc, x.tick);
   if constexpr (BM == 64 && BN == 64 && !NCHW) {
     if (x.sk_G) {
       static int attr_dev_mask_p = 0;
@@ -1732,7 +1712,7 @@ static std::string tune_key(const GemmParams& p, int kind, int nchw) {
   snprintf(buf, sizeof(buf), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", kind, nchw, p.M, p.N, p.K,
            p.g_KH * p.g_KW, p.g_stride, p.g_Cs, p.a_pro, p.b_pro, p.epi_mode, p.act | (p.dact << 4),
            (p.stat1 ? 1 : 0) | (p.stat2 ? 2 : 0) | (p.Mk ? 4 : 0) | (p.R ? 8 : 0) | (p.Cpre ? 16 : 0) |
-               (p.colsum ? 32 : 0) | (p.bias ? 64 : 0) | (p.sk_ws ? 128 : 0) | (p.a_fold.stat ? 256 : 0) | (p.sk_cnt ? 512 : 0) | (p.A_out ? 1024 : 0),
+               (p.colsum ? 32 : 0) | (p.bias ? 64 : 0) | (p.sk_ws ? 128 : 0) | (p.a_fold.stat ? 256 : 0) | (p.sk_cnt ? 512 : 0),
            p.c_atomic, p.splitk);
   return buf;
 }
@@ -1769,19 +1749,11 @@ static int validate_desc(const GemmParams& p, int kind, int nchw) {
     const mmvqa_bn_fold& f = p.a_fold;
     if (f.slots <= 0 || f.slots > MMVQA_STAT_SLOTS || (f.slots & (f.slots - 1))) BAD("a_fold.slots=%d is not a power of two <= %d", f.slots, MMVQA_STAT_SLOTS);
     if (!(f.count > 0.0) || !f.gamma) BAD("a_fold without count / gamma");
-    if (f.bwd ? (p.a_pro != PRO_DZ || !f.mean || !f.invstd) : ((p.a_pro != PRO_AFFINE_RELU && p.a_pro != PRO_BLOCK_END) || !f.beta)) BAD("a_fold.bwd=%d does not match A prologue %d (or mean / invstd / beta missing)", f.bwd, p.a_pro);
+    if (f.bwd ? (p.a_pro != PRO_DZ || !f.mean || !f.invstd) : (p.a_pro != PRO_AFFINE_RELU || !f.beta)) BAD("a_fold.bwd=%d does not match A prologue %d (or mean / invstd / beta missing)", f.bwd, p.a_pro);
     if (f.publish && (!f.out0 || !f.out1 || !f.out2 || (f.bwd ? (!f.dgamma || !f.dbeta) : !f.out3))) BAD("a_fold.publish without output arrays");
     if (nchw && kind != KIND_WGRAD) BAD("a_fold: not for the NCHW stem forward");
   } else if (p.a_pro != PRO_NONE && (!p.a_c0 || !p.a_c1)) BAD("A prologue %d without coefficients", p.a_pro);
-  if ((p.a_pro == PRO_DZ || p.a_pro == PRO_BLOCK_END) && (!p.A2 || (!p.a_c2 && !p.a_fold.stat))) BAD("two-tensor prologue %d without A2 / c2", p.a_pro);
-  if (p.a_pro == PRO_BLOCK_END && kind != KIND_FWD) BAD("the block-end prologue is a forward prologue");
-  if (p.a_fold2.stat) {
-    const mmvqa_bn_fold& f = p.a_fold2;
-    if (p.a_pro != PRO_BLOCK_END || !p.a_fold.stat) BAD("a_fold2 without the block-end prologue and a_fold");
-    if (f.bwd || f.slots <= 0 || f.slots > MMVQA_STAT_SLOTS || (f.slots & (f.slots - 1)) || !(f.count > 0.0) || !f.gamma || !f.beta) BAD("a_fold2: bad forward fold");
-    if (f.publish && (!f.out0 || !f.out1 || !f.out2 || !f.out3)) BAD("a_fold2.publish without output arrays");
-  }
-  if (p.A_out && p.a_pro != PRO_BLOCK_END) BAD("A_out without the block-end prologue");
+  if (p.a_pro == PRO_DZ && (!p.A2 || (!p.a_c2 && !p.a_fold.stat))) BAD("BatchNorm-backward prologue without A2 / c2");
   if (p.stat_slots < 0 || p.stat_slots > MMVQA_STAT_SLOTS || (p.stat_slots & (p.stat_slots - 1))) BAD("stat_slots=%d is not a power of two <= %d", p.stat_slots, MMVQA_STAT_SLOTS);
   if (p.b_pro != PRO_NONE && (!p.b_c0 || !p.b_c1)) BAD("B prologue %d without coefficients", p.b_pro);
   if ((p.a_pro == PRO_SILU_GATE || p.b_pro == PRO_SILU_GATE) && (!p.gate || p.gate_hw <= 0)) BAD("gate prologue without gate tensor");
@@ -1834,6 +1806,8 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     float best = 1e30f, best_single = 1e30f;
     Cand bc = cands[0], bc_single = cands[0];
     const bool sk_partial = kind != KIND_WGRAD && sk_eligible(p, kind) && p.splitk <= 0;
+    // (0.85 with the finishing launch; the ticketed form has no second launch, but still takes CUs from the other stream)
+    static const float sk_gain = getenv("MMVQA_SK_GAIN") ? (float)atof(getenv("MMVQA_SK_GAIN")) : (getenv("MMVQA_SK_FINISH") ? 0.85f : 0.92f);
     for (const Cand& c : cands) {
       GemmParams q = p;
       q.splitk = c.splitk;
@@ -1852,7 +1826,7 @@ int mmvqa_launch_igemm(GemmParams p, int kind, int nchw, int tile, hipStream_t s
     }
     // K split with a finishing launch is timed here on an empty chip; inside the step it costs a second launch on the
     // dependency chain and takes the CUs the other stream would use: only worth it when clearly faster
-    if (sk_partial && bc.splitk > 1 && best_single < 1e29f && best > 0.85f * best_single) { bc = bc_single; best = best_single; }
+    if (sk_partial && bc.splitk > 1 && best_single < 1e29f && best > sk_gain * best_single) { bc = bc_single; best = best_single; }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     it = g_tuner->table.emplace(key, IgemmChoice{bc.tile, bc.splitk, bc.persist}).first;

@@ -195,15 +195,6 @@ def test_full_width_hidden768():
              hw=64, kind="mlm")
 
 
-def test_block_end_fused_into_the_next_conv1(monkeypatch):
-    """MMVQA_FUSED_BLOCK_END=1 (opt-in, time-neutral: DESIGN 4.2): conv1 of every Bottleneck applies the previous block's
-    relu(bn3(z3) + identity) on load and materialises it; full channel widths (the fusion needs multiples of 64), two
-    blocks per layer so that identity and downsample ends, layer ends with taps and the last block's own launch all occur"""
-    monkeypatch.setenv("MMVQA_FUSED_BLOCK_END", "1")
-    run_case(mini_args(resnet_layers=(2, 2, 2, 2), resnet_width=64, hidden_size=768, n_layers=1, vocab_size=300, emb_vocab=300),
-             B=2, T=32, hw=64, kind="mlm", stat_tol=TOL)
-
-
 def test_full_config2_resnet152_224():
     """BASELINE.json configs[1] itself: resnet152 at full depth and width, 224x224, hidden 768, 4 layers, T 32,
     vocab 30522 -- forward, loss, every gradient and the BatchNorm buffers against the oracle (batch 2 keeps the

@@ -235,10 +235,13 @@ def test_conv_fwd_bwd(cfg):
 @pytest.mark.parametrize("cfg,tile", [((2, 7, 7, 256, 72, 1, 1, 0), 3), ((2, 7, 7, 256, 72, 1, 1, 0), 5), ((1, 7, 7, 128, 40, 3, 1, 1), 6),
                                       ((3, 6, 6, 192, 52, 1, 1, 0), 3)])
 @pytest.mark.parametrize("splitk", [2, 3, 8])
-def test_conv_split_k_with_finishing_launch(cfg, tile, splitk):
+@pytest.mark.parametrize("ticket", [False, True])
+def test_conv_split_k_with_finishing_launch(cfg, tile, splitk, ticket):
     """forward / data-gradient products with few output tiles and a long contraction: K split over workgroups into a
     caller-provided scratch (sk_ws) + the finishing launch that sums the partial tiles and runs the WHOLE epilogue
-    (BN statistics forward and backward, ReLU mask, residual).  Same answers as the single launch and as torch; ragged
+    (BN statistics forward and backward, ReLU mask, residual).  ticket=True: with the caller's tickets (sk_cnt) there is
+    no second launch -- the last workgroup of a tile to arrive sums the partial tiles and runs the epilogue; the
+    tickets must be zero again afterwards.  Same answers as the single launch and as torch; ragged
     N (72, 52, 40: not multiples of 64), a split count that does not divide the K-tiles, and a
     scratch too small for the requested split (the launcher lowers the split instead of overrunning it)."""
     N, H, W, Cin, Cout, K, s, p = cfg
@@ -252,7 +255,13 @@ def test_conv_split_k_with_finishing_launch(cfg, tile, splitk):
     xd, wd = nhwc(x_raw), w_ohwi(w)
     scd, shd = sc.to(dev()), sh.to(dev())
     M = N * OH * OW
-    ws = torch.full((splitk * M * Cout + 16,), float("nan"), device=dev())   # NaN: every partial element must be written
+    pad = lambda m, n: ((m + 63) // 64) * ((n + 63) // 64) * 4096   # the ticketed form keeps whole tiles
+    ws = torch.full((splitk * (pad(M, Cout) if ticket else M * Cout) + 16,), float("nan"), device=dev())   # NaN: every partial element must be written
+    cnt = torch.zeros(256, dtype=torch.int32, device=dev())
+
+    def tickets(d):
+        if ticket:
+            d.sk_cnt, d.sk_cnt_n = P(cnt), cnt.numel()
     res = {}
     for sk in (1, splitk):
         z = torch.zeros(M, Cout, device=dev())
@@ -260,7 +269,8 @@ def test_conv_split_k_with_finishing_launch(cfg, tile, splitk):
         d, _, _ = conv_desc_fwd(xd, wd, N, H, W, Cin, Cout, K, s, p, z)
         d.a_pro, d.a_c0, d.a_c1 = L.PRO_AFFINE_RELU, P(scd), P(shd)
         d.stat1, d.stat_bwd = P(stat), 0
-        d.splitk, d.sk_ws, d.sk_ws_floats = sk, P(ws), splitk * M * Cout
+        d.splitk, d.sk_ws, d.sk_ws_floats = sk, P(ws), ws.numel() - 16
+        tickets(d)
         run_igemm(d, L.KIND_FWD, tile=tile)
         res[sk] = (z, stat.sum(0).cpu())
     assert_close(from_nhwc(res[splitk][0], N, OH, OW, Cout), z_ref, TOL, "z (split-K)")
@@ -276,9 +286,10 @@ def test_conv_split_k_with_finishing_launch(cfg, tile, splitk):
     mu, istd = torch.randn(Cin) * 0.1, torch.rand(Cin) + 0.5
     mud, isd = mu.to(dev()), istd.to(dev())
     M2 = N * H * W
-    ws2 = torch.full((splitk * M2 * Cin,), float("nan"), device=dev())
+    full = splitk * (pad(M2, Cin) if ticket else M2 * Cin)
+    ws2 = torch.full((full,), float("nan"), device=dev())
     out = {}
-    for sk, cap in ((1, splitk * M2 * Cin), (splitk, splitk * M2 * Cin), (splitk, 2 * M2 * Cin)):
+    for sk, cap in ((1, full), (splitk, full), (splitk, 2 * M2 * Cin)):
         dx = torch.zeros(M2, Cin, device=dev())
         bst = torch.zeros(L.STAT_SLOTS, Cin, 2, dtype=torch.float64, device=dev())
         d = conv_desc_dgrad(Gd, wd, N, H, W, Cin, Cout, K, s, p, dx)
@@ -286,8 +297,10 @@ def test_conv_split_k_with_finishing_launch(cfg, tile, splitk):
         d.R, d.r_ld = P(Rd), Cin
         d.stat1, d.stat_bwd, d.Z1, d.z1_ld, d.mean1, d.invstd1 = P(bst), 1, P(xd), Cin, P(mud), P(isd)
         d.splitk, d.sk_ws, d.sk_ws_floats = sk, P(ws2), cap
+        tickets(d)
         run_igemm(d, L.KIND_DGRAD, tile=tile)
         out[(sk, cap)] = (dx, bst.sum(0).cpu())
+    assert int(cnt.abs().sum()) == 0, "tickets not back at zero"
     mask = (x_raw * sc[None, :, None, None] + sh[None, :, None, None] > 0).float()
     g_ref = (a.grad + Rr.view(N, H, W, Cin).permute(0, 3, 1, 2)) * mask
     xhat = (x_raw - mu[None, :, None, None]) * istd[None, :, None, None]
@@ -696,64 +709,6 @@ def test_block_end_with_folded_batchnorms():
         if with_d:
             assert_close(keep[1][5], bd.running_var, 1e-5, "downsample bn running var")
             assert_close(keep[1][3][0], bd.weight.detach() / torch.sqrt(zd.var(dim=(0, 2, 3), unbiased=False) + 1e-5), 1e-5, "bn_d scale")
-
-
-@pytest.mark.parametrize("N,H,W,Cin,Cout,slots,with_d,tile", [(2, 7, 7, 256, 64, 4, False, 0), (3, 6, 6, 128, 128, 2, True, 5),
-                                                             (2, 9, 9, 64, 192, 1, True, 6), (1, 14, 14, 1024, 256, 4, False, 3)])
-def test_block_end_applied_by_the_next_conv1(N, H, W, Cin, Cout, slots, with_d, tile):
-    """a_pro = 6 (MMVQA_PRO_BLOCK_END): conv1 of the next Bottleneck forms relu(bn3(z3) + [bn_d](identity)) while it loads
-    its input, writes that tensor to A_out (column block 0 only, every element once) and folds both BatchNorms from
-    their raw sums, publishing running statistics -- against torch (train-mode BatchNorm2d, k-fold running statistics)
-    and against precomputed coefficients."""
-    torch.manual_seed(13)
-    z3, idn = torch.randn(N, Cin, H, W) * 2 + 0.5, torch.randn(N, Cin, H, W) * 0.7 - 0.2
-    b3, bd = torch.nn.BatchNorm2d(Cin).train(), torch.nn.BatchNorm2d(Cin).train()
-    with torch.no_grad():
-        for m in (b3, bd):
-            m.weight.uniform_(0.5, 1.5)
-            m.bias.normal_(0, 0.3)
-    w = torch.randn(Cout, Cin, 1, 1) / math.sqrt(Cin)
-    out_ref = torch.relu(b3(z3) + (bd(idn) if with_d else idn))
-    z_ref = F.conv2d(out_ref, w)
-    M = N * H * W
-    z3d, idnd, wd = nhwc(z3), nhwc(idn), w_ohwi(w)
-    folds, keep = [], []
-    for zt, m in ((z3, b3), (idn, bd)):
-        sums = torch.stack([zt.double().sum(dim=(0, 2, 3)), (zt.double() ** 2).sum(dim=(0, 2, 3))], 1)
-        outs = [torch.zeros(Cin, device=dev()) for _ in range(4)]
-        rm, rv = torch.zeros(Cin, device=dev()), torch.ones(Cin, device=dev())
-        nbt = torch.zeros(1, dtype=torch.int64, device=dev())
-        st, g, b = _spread(sums, slots), m.weight.detach().to(dev()), m.bias.detach().to(dev())
-        keep.append((st, g, b, outs, rm, rv, nbt))
-        folds.append(_fold(st, slots, 0, 1, M, g, beta=b, out0=outs[0], out1=outs[1], out2=outs[2], out3=outs[3],
-                           run_mean=rm, run_var=rv, nbt=nbt))
-    zo = torch.zeros(M, Cout, device=dev())
-    a_out = torch.full((M, Cin), float("nan"), device=dev())
-    stat = torch.zeros(L.STAT_SLOTS, Cout, 2, dtype=torch.float64, device=dev())
-    d, _, _ = conv_desc_fwd(z3d, wd, N, H, W, Cin, Cout, 1, 1, 0, zo)
-    d.A2, d.a_pro, d.A_out = P(idnd), L.PRO_BLOCK_END, P(a_out)
-    d.a_fold = folds[0]
-    if with_d:
-        d.a_fold2 = folds[1]
-    d.stat1, d.stat_bwd = P(stat), 0
-    run_igemm(d, L.KIND_FWD, tile=tile)
-    assert_close(from_nhwc(a_out, N, H, W, Cin), out_ref, TOL, "materialised block output")
-    assert_close(from_nhwc(zo, N, H, W, Cout), z_ref, TOL, "conv1 on the block end formed on load")
-    assert_close(stat.sum(0).cpu()[:, 0], z_ref.sum(dim=(0, 2, 3)).double(), 1e-5, "statistics of conv1's output")
-    assert_close(keep[0][5], b3.running_var, 1e-5, "bn3 running var")
-    assert int(keep[0][6]) == 1 and int(keep[1][6]) == (1 if with_d else 0)
-    if with_d:
-        assert_close(keep[1][4], bd.running_mean, 1e-5, "bn_d running mean")
-    # the same launch on precomputed coefficients: c0 = scale3, c1 = scale_d | 1, c2 = shift3 + shift_d
-    c0 = keep[0][3][0]
-    c1 = keep[1][3][0] if with_d else torch.ones(Cin, device=dev())
-    c2 = keep[0][3][1] + (keep[1][3][1] if with_d else 0.0)
-    zo2, a_out2 = torch.zeros_like(zo), torch.zeros_like(a_out)
-    d, _, _ = conv_desc_fwd(z3d, wd, N, H, W, Cin, Cout, 1, 1, 0, zo2)
-    d.A2, d.a_pro, d.A_out, d.a_c0, d.a_c1, d.a_c2 = P(idnd), L.PRO_BLOCK_END, P(a_out2), P(c0), P(c1), P(c2)
-    run_igemm(d, L.KIND_FWD, tile=tile)
-    assert_close(zo2, zo, 1e-6, "folded vs precomputed coefficients")
-    assert_close(a_out2, a_out, 1e-6, "block output, folded vs precomputed coefficients")
 
 
 def test_maxpool():
