@@ -333,7 +333,7 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
       if (blk.feature >= 0) { e->taps[blk.feature].HW = blk.OH * blk.OW; e->taps[blk.feature].M = (long)Mout; }
       h = blk.OH; wd = blk.OW;
     }
-    e->eff_gA = a.f(max_mid); e->eff_gB = a.f(max_mid);
+    for (int k = 0; k < 2; ++k) { e->eff_gA[k] = a.f(max_mid); e->eff_gB[k] = a.f(max_mid); }
     for (int i = 0; i < 6; ++i) e->eff_se[i] = a.f(max_se + 64);
     e->eff_separt = a.f(max_separt + 64);
     for (int k = 0; k < 5; ++k) {
@@ -1104,6 +1104,7 @@ static int effnet_forward(mmvqa_engine* e, hipStream_t st) {
                                     nullptr, 0, ACT_NONE, WS(e->eff_a0), M0, 24));
   }
   const float* x = WS(e->eff_a0);
+  SideCtx sc(e, st);
   for (auto& b : e->eff) {
     const long Mout = (long)B * b.OH * b.OW;
     const float* idn = b.skip ? x : nullptr;
@@ -1133,8 +1134,10 @@ static int effnet_forward(mmvqa_engine* e, hipStream_t st) {
                                       ACT_NONE, WS(b.out), Mout, b.cout));
     }
     x = WS(b.out);
-    if (b.feature >= 0) TRY(tap_fwd(e, st, b.feature, x, nullptr));
+    // the taps feed only the encoder: side stream, beside the chain of (mostly sub-chip-sized) launches
+    if (b.feature >= 0) { sc.fork(); TRY(tap_fwd(e, sc.sd, b.feature, x, nullptr)); }
   }
+  sc.need(sc.mark());   // join: the embedding reads the visual tokens
   return MMVQA_OK;
 }
 
@@ -1143,7 +1146,15 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
   HIP_CHECK_RET(hipMemsetAsync(stat_ptr(e, 0) + e->statzone_floats / 4, 0,
                                e->statzone_floats / 2 * sizeof(float), st));
   const int nb = (int)e->eff.size();
+  // Weight gradients (convolutions, depthwise, taps) only feed the optimizer: they run on the side stream beside the
+  // data-gradient chain, whose launches are mostly smaller than the chip.  A side launch starts after everything the
+  // caller's stream had queued when it was issued (fork) and leaves an event behind; the chain waits for that event before
+  // it overwrites a buffer the side launch reads (G alternates between the two gbuf, gA / gB between two copies by block
+  // parity, so the wait is for the launch of two blocks ago).
   SideCtx scx(e, st);
+  hipStream_t sd = scx.sd;
+  hipEvent_t ev_G[2] = {nullptr, nullptr}, ev_gA[2] = {nullptr, nullptr}, ev_gB[2] = {nullptr, nullptr};
+  hipEvent_t ev_tap[4] = {nullptr, nullptr, nullptr, nullptr};
   long long hi_mark = e->enc_lo;
   // a block whose last op is a BatchNorm (er / ir) expects the BN-backward sums of that BN with its gradient
   auto producer_opts = [&](int i, EpiOpt& o) {
@@ -1151,14 +1162,20 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
     EffBlock& pb = e->eff[i];
     if (pb.type != 0) { o.st1 = &pb.b_p; o.Z1 = WS(pb.zp); }
   };
-  for (auto& b : e->eff)
-    if (b.feature >= 0 && b.feature < 4) TRY(tap_bwd(e, st, b.feature, WS(b.out), nullptr, WS(e->tapgrad[b.feature]), EpiOpt()));
   int cur = 0;
   {
     EpiOpt o;
     producer_opts(nb - 1, o);
     TRY(tap_bwd(e, st, 4, WS(e->eff[nb - 1].out), nullptr, WS(e->gbuf[cur]), o));
   }
+  // the other taps produce side gradients that are needed when the chain reaches their block (they share the `du`
+  // scratch with the tap above, hence the fork after it)
+  scx.fork();
+  for (auto& b : e->eff)
+    if (b.feature >= 0 && b.feature < 4) {
+      TRY(tap_bwd(e, sd, b.feature, WS(b.out), nullptr, WS(e->tapgrad[b.feature]), EpiOpt()));
+      ev_tap[b.feature] = scx.mark();
+    }
   for (int i = nb - 1; i >= 0; --i) {
     EffBlock& b = e->eff[i];
     const float* G = WS(e->gbuf[cur]);
@@ -1167,18 +1184,23 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
     const float* extra = (i > 0 && e->eff[i - 1].feature >= 0) ? WS(e->tapgrad[e->eff[i - 1].feature]) : nullptr;
     if (extra && b.skip) return mmvqa_set_error(MMVQA_ERR_STATE, "effnet_backward: tap gradient into a skip block");
     const long Min = (long)B * b.H * b.W, Mout = (long)B * b.OH * b.OW;
-    float* gA = WS(e->eff_gA);
-    float* gB = WS(e->eff_gB);
+    const int pi = i & 1;
+    float* gA = WS(e->eff_gA[pi]);
+    float* gB = WS(e->eff_gB[pi]);
     const float* dz_first = nullptr;   // gradient tensor feeding the block's first convolution
     if (b.type == 0) {
       // out = silu(bn(za)) + x
+      scx.need(ev_gA[pi]);
       RUNB(HB_ACT_BWD_STATS, 12.0 * Mout * b.cout, k_act_bwd_stats(st, G, nullptr, nullptr, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift),
                                          WS(b.b_a.mean), WS(b.b_a.invstd), ACT_SILU, gA, stat_ptr(e, b.b_a.stat_b), Mout,
                                          b.OH * b.OW, b.cout));
       dz_first = gA;
     } else if (b.type == 1) {
       TRY(bn_coef_bwd(e, st, b.b_p));
-      TRY(eff_conv_wgrad(e, st, b.c_p, G, WS(b.zp), b.b_p, WS(b.za), &b.b_a, nullptr, B, b.OH, b.OW, b.OH, b.OW));
+      scx.fork();
+      TRY(eff_conv_wgrad(e, sd, b.c_p, G, WS(b.zp), b.b_p, WS(b.za), &b.b_a, nullptr, B, b.OH, b.OW, b.OH, b.OW));
+      ev_G[cur] = scx.mark();
+      scx.need(ev_gA[pi]);
       EpiOpt o;
       o.Mk = WS(b.za); o.mk_ld = b.mid; o.mk_s = WS(b.b_a.scale); o.mk_b = WS(b.b_a.shift); o.mk_mode = 1;
       o.st1 = &b.b_a; o.Z1 = WS(b.za);
@@ -1186,7 +1208,10 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
       dz_first = gA;
     } else {
       TRY(bn_coef_bwd(e, st, b.b_p));
-      TRY(eff_conv_wgrad(e, st, b.c_p, G, WS(b.zp), b.b_p, WS(b.zdw), &b.b_dw, WS(b.gate), B, b.OH, b.OW, b.OH, b.OW));
+      scx.fork();
+      TRY(eff_conv_wgrad(e, sd, b.c_p, G, WS(b.zp), b.b_p, WS(b.zdw), &b.b_dw, WS(b.gate), B, b.OH, b.OW, b.OH, b.OW));
+      ev_G[cur] = scx.mark();
+      scx.need(ev_gA[pi]);
       TRY(conv_dgrad(e, st, b.c_p, G, WS(b.zp), b.b_p, B, b.OH, b.OW, b.OH, b.OW, gA, EpiOpt()));   // t = d(a2*gate)
       // squeeze-excite backward
       float* dgate = WS(e->eff_se[0]); float* dpool = WS(e->eff_se[3]);
@@ -1196,13 +1221,19 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
                                      GRD(b.se_e.w), GRD(b.se_e.b), GRD(b.se_r.w), GRD(b.se_r.b), dpool,
                                      WS(e->eff_separt), 1, B, b.mid, b.rd));
       // du2 = (t*gate + dpool/HW) * silu'(bn2(zdw)); BN2 sums
+      scx.need(ev_gB[pi]);
       RUNB(HB_ACT_BWD_STATS, 12.0 * Mout * b.mid, k_act_bwd_stats(st, gA, WS(b.gate), dpool, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift),
                                          WS(b.b_dw.mean), WS(b.b_dw.invstd), ACT_SILU, gB, stat_ptr(e, b.b_dw.stat_b), Mout,
                                          b.OH * b.OW, b.mid));
       TRY(bn_coef_bwd(e, st, b.b_dw));
-      RUNB(HB_DWCONV_BWD_WEIGHT, 4.0 * (2.0 * Mout + (double)Min) * b.mid, k_dwconv_bwd_weight(st, gB, WS(b.zdw), WS(b.b_dw.P), WS(b.b_dw.Q), WS(b.b_dw.R), WS(b.za),
+      scx.fork();
+      {
+        hipStream_t st = sd;   // (RUNB times / launches on `st`)
+        RUNB(HB_DWCONV_BWD_WEIGHT, 4.0 * (2.0 * Mout + (double)Min) * b.mid, k_dwconv_bwd_weight(st, gB, WS(b.zdw), WS(b.b_dw.P), WS(b.b_dw.Q), WS(b.b_dw.R), WS(b.za),
                                              WS(b.b_a.scale), WS(b.b_a.shift), GRD(b.dw_w), B, b.H, b.W, b.mid, b.OH, b.OW,
                                              b.stride, b.pad));
+      }
+      ev_gB[pi] = scx.mark();
       RUNB(HB_DWCONV_BWD_DATA, 4.0 * (2.0 * Mout + 2.0 * (double)Min) * b.mid, k_dwconv_bwd_data(st, gB, WS(b.zdw), WS(b.b_dw.P), WS(b.b_dw.Q), WS(b.b_dw.R), PRM(b.dw_w),
                                            WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), WS(b.b_a.mean), WS(b.b_a.invstd), gA,
                                            stat_ptr(e, b.b_a.stat_b), B, b.H, b.W, b.mid, b.OH, b.OW, b.stride, b.pad));
@@ -1211,11 +1242,14 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
     // first convolution of the block: weight gradient, then the gradient wrt the block input
     TRY(bn_coef_bwd(e, st, b.b_a));
     const int fo_h = b.type == 2 ? b.H : b.OH, fo_w = b.type == 2 ? b.W : b.OW;   // its output resolution
-    TRY(eff_conv_wgrad(e, st, b.c_a, dz_first, WS(b.za), b.b_a, x, nullptr, nullptr, B, b.H, b.W, fo_h, fo_w));
+    scx.fork();
+    TRY(eff_conv_wgrad(e, sd, b.c_a, dz_first, WS(b.za), b.b_a, x, nullptr, nullptr, B, b.H, b.W, fo_h, fo_w));
+    ev_gA[pi] = scx.mark();
     EpiOpt o;
     producer_opts(i - 1, o);
     if (b.skip) { o.R = G; o.r_ld = b.cin; }
-    else if (extra) { o.R = extra; o.r_ld = b.cin; }
+    else if (extra) { o.R = extra; o.r_ld = b.cin; scx.need(ev_tap[e->eff[i - 1].feature]); }
+    scx.need(ev_G[cur ^ 1]);   // the buffer written next was the G of the block before: its side reader must be done
     TRY(conv_dgrad(e, st, b.c_a, dz_first, WS(b.za), b.b_a, B, b.H, b.W, fo_h, fo_w, Gprev, o));
     (void)Min;
     cur ^= 1;
@@ -1224,6 +1258,7 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
   // stem: du0 = G(a0) * silu'(bn1(z0)); BN sums; 3x3 weight gradient on the NCHW image
   float* g0 = WS(e->gbuf[cur ^ 1]);
   const long M0 = (long)B * e->SH * e->SW;
+  scx.need(ev_G[cur ^ 1]);
   RUNB(HB_ACT_BWD_STATS, 12.0 * M0 * 24, k_act_bwd_stats(st, WS(e->gbuf[cur]), nullptr, nullptr, WS(e->z0), WS(e->stem_bn.scale),
                                      WS(e->stem_bn.shift), WS(e->stem_bn.mean), WS(e->stem_bn.invstd), ACT_SILU, g0,
                                      stat_ptr(e, e->stem_bn.stat_b), M0, e->SH * e->SW, 24));
@@ -1240,6 +1275,7 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
     g.C = GRD(e->stem_conv.w); g.c_ld = 27; g.c_atomic = 1;
     RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_WGRAD, 1, 0, st));
   }
+  scx.need(scx.mark());   // join: everything after the backward (all-reduce, Adam) sees the side stream's gradients
   notify(e, scx, e->emb_hi, hi_mark);
   return MMVQA_OK;
 }

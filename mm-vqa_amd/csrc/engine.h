@@ -111,7 +111,8 @@ struct mmvqa_engine {
   std::vector<EffBlock> eff;     // EfficientNetV2 body (cnn == 1)
   size_t eff_a0 = 0;             // materialised stem activation silu(bn1(conv_stem))
   size_t sk_ws[2] = {0, 0};      // split-K partial-tile scratch per stream (igemm sk_ws)
-  size_t eff_gA = 0, eff_gB = 0, eff_separt = 0, eff_se[6];   // backward scratch ([pixels, mid] x2, squeeze-excite temporaries)
+  size_t eff_gA[2] = {0, 0}, eff_gB[2] = {0, 0}, eff_separt = 0, eff_se[6];   // backward scratch ([pixels, mid], two of each: blocks alternate,
+                                                                            // the side stream still reads block i's while block i-1 writes), squeeze-excite temporaries
   int layer_end[4];          // index of last block of layer1..4
   TapRef taps[5];            // order of the reference's return tuple: conv2(l4),conv3(l3),conv4(l2),conv5(l1),conv7(stem)
   long long emb_word = 0, emb_pos = 0, emb_type = 0;
