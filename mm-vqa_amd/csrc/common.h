@@ -169,6 +169,26 @@ __device__ __forceinline__ void bn_fold_fwd(const BnFold& f, int C, int c, bool 
   }
 }
 
+// scale / shift of the NCH consecutive channels from c0 that a workgroup of an elementwise kernel works on, into LDS:
+// from the coefficient arrays, or folded from the raw sums (thread t < NCH folds channel c0 + t once for the workgroup --
+// every thread folding its own quad cost 16 replicas x 16 B x 4 channels of L2 reads per THREAD and lost to the separate
+// coefficient launch).  `pub`: this workgroup also publishes.  All threads call it; ends with a barrier.
+template <int NCH>
+__device__ __forceinline__ void bn_coef_block_fwd(const float* __restrict__ s, const float* __restrict__ b, const BnFold& f,
+                                                  int C, int c0, bool pub, float (*cf)[NCH]) {
+  const int t = threadIdx.x;
+  if (t < NCH) {
+    float a = 0.f, d = 0.f;
+    const int c = c0 + t;
+    if (c < C) {
+      if (f.stat) bn_fold_fwd(f, C, c, pub, a, d);
+      else { a = s[c]; d = b[c]; }
+    }
+    cf[0][t] = a; cf[1][t] = d;
+  }
+  __syncthreads();
+}
+
 // backward: (sum g, sum g*xhat) -> dz = P*g + Q*z + R ; published: P, Q, R and dgamma += sum g*xhat, dbeta += sum g
 __device__ __forceinline__ void bn_fold_bwd(const BnFold& f, int C, int c, bool pub, float& P, float& Q, float& R) {
   double sg, sgx;

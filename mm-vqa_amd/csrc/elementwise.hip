@@ -992,6 +992,9 @@ int k_bn_coef_fwd(hipStream_t st, const double* stat, int C, double count, float
 // Block end with the coefficients of bn3 (and of the downsample BatchNorm) folded from their raw sums (mmvqa_bn_fold):
 // no coefficient launch between conv3 and this kernel.  One workgroup = 64 channels x `rpw` rows; 64 (+64) threads fold
 // one channel each into LDS; the workgroups of row block 0 publish scale / shift / mean / invstd / running statistics.
+// out = POST(PRE(bn(z)) + idn'),  idn' = bn_d(idn) | idn | nothing:  ResNet Bottleneck <NONE, RELU>, the EfficientNet
+// blocks <SILU, NONE> / <NONE, NONE> (models/image_encoding.py:72-86, 89-115)
+template <int PRE, int POST>
 __global__ __launch_bounds__(256) void bn_add_relu_fold_kernel(const float* __restrict__ z, const BnFold f3,
                                                                const float* __restrict__ idn, const BnFold fd, int has_d,
                                                                float* __restrict__ out, long rows, int C, int rpw) {
@@ -1018,29 +1021,30 @@ __global__ __launch_bounds__(256) void bn_add_relu_fold_kernel(const float* __re
   const f32x4 s3 = *reinterpret_cast<const f32x4*>(&cs[0][q * 4]), b3 = *reinterpret_cast<const f32x4*>(&cs[1][q * 4]);
   const f32x4 sd = *reinterpret_cast<const f32x4*>(&cs[2][q * 4]), bd = *reinterpret_cast<const f32x4*>(&cs[3][q * 4]);
   const long r0 = (long)blockIdx.x * rpw, r1 = r0 + rpw < rows ? r0 + rpw : rows;
+  const f32x4 zero = {0, 0, 0, 0};
   for (long r = r0 + rl; r < r1; r += 32) {
     const long i0 = r * C + c, i1 = (r + 16) * C + c;
     const bool two = r + 16 < r1;
-    const f32x4 z0 = *reinterpret_cast<const f32x4*>(z + i0), d0 = *reinterpret_cast<const f32x4*>(idn + i0);
+    const f32x4 z0 = *reinterpret_cast<const f32x4*>(z + i0), d0 = idn ? *reinterpret_cast<const f32x4*>(idn + i0) : zero;
     f32x4 z1 = z0, d1 = d0;
-    if (two) { z1 = *reinterpret_cast<const f32x4*>(z + i1); d1 = *reinterpret_cast<const f32x4*>(idn + i1); }
+    if (two) { z1 = *reinterpret_cast<const f32x4*>(z + i1); if (idn) d1 = *reinterpret_cast<const f32x4*>(idn + i1); }
     f32x4 o0, o1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float t0 = z0[j] * s3[j] + b3[j] + (d0[j] * sd[j] + bd[j]);
-      const float t1 = z1[j] * s3[j] + b3[j] + (d1[j] * sd[j] + bd[j]);
-      o0[j] = t0 > 0.f ? t0 : 0.f;
-      o1[j] = t1 > 0.f ? t1 : 0.f;
+      const float t0 = act_fwd(PRE, z0[j] * s3[j] + b3[j]) + (d0[j] * sd[j] + bd[j]);
+      const float t1 = act_fwd(PRE, z1[j] * s3[j] + b3[j]) + (d1[j] * sd[j] + bd[j]);
+      o0[j] = act_fwd(POST, t0);
+      o1[j] = act_fwd(POST, t1);
     }
     *reinterpret_cast<f32x4*>(out + i0) = o0;
     if (two) *reinterpret_cast<f32x4*>(out + i1) = o1;
   }
 }
 
-int k_bn_add_relu_fold(hipStream_t st, const float* z, const mmvqa_bn_fold* f3, const float* idn, const mmvqa_bn_fold* fd,
-                       float* out, long rows, int C) {
-  if (C % 4 != 0 || !f3 || !f3->stat || f3->bwd || (fd && (!fd->stat || fd->bwd)))
-    return mmvqa_set_error(MMVQA_ERR_ARG, "bn_add_relu_fold: C=%d must be a multiple of 4 and the folds forward ones", C);
+int k_bn_act_add_fold(hipStream_t st, const float* z, const mmvqa_bn_fold* f3, int pre_act, const float* idn,
+                      const mmvqa_bn_fold* fd, int post_act, float* out, long rows, int C) {
+  if (C % 4 != 0 || !f3 || !f3->stat || f3->bwd || (fd && (!fd->stat || fd->bwd || !idn)))
+    return mmvqa_set_error(MMVQA_ERR_ARG, "bn_act_add_fold: C=%d must be a multiple of 4 and the folds forward ones", C);
   const int cb = cdiv_i(C, 64);
   // rows per workgroup: every workgroup pays the fold of its 64 channels (~1.5 us of setup) before it streams its rows, so
   // few, long workgroups; MMVQA_BAR_WGS = target number of workgroups (A/B)
@@ -1049,10 +1053,23 @@ int k_bn_add_relu_fold(hipStream_t st, const float* z, const mmvqa_bn_fold* f3, 
   while ((long)cdiv_i(rows, rpw) * cb > target && rpw < 1024) rpw *= 2;
   mmvqa_bn_fold none;
   memset(&none, 0, sizeof(none));
-  hipLaunchKernelGGL(bn_add_relu_fold_kernel, dim3(cdiv_i(rows, rpw), cb), dim3(256), 0, st, z, *f3, idn, fd ? *fd : none,
-                     fd ? 1 : 0, out, rows, C, rpw);
+  const dim3 grid(cdiv_i(rows, rpw), cb);
+#define BAR_GO(PRE_, POST_)                                                                                            \
+  hipLaunchKernelGGL((bn_add_relu_fold_kernel<PRE_, POST_>), grid, dim3(256), 0, st, z, *f3, idn, fd ? *fd : none, fd ? 1 : 0, \
+                     out, rows, C, rpw)
+  if (pre_act == ACT_NONE && post_act == ACT_RELU) BAR_GO(ACT_NONE, ACT_RELU);
+  else if (pre_act == ACT_SILU && post_act == ACT_NONE) BAR_GO(ACT_SILU, ACT_NONE);
+  else if (pre_act == ACT_NONE && post_act == ACT_NONE) BAR_GO(ACT_NONE, ACT_NONE);
+  else return mmvqa_set_error(MMVQA_ERR_ARG, "bn_act_add_fold: activation pair (%d, %d) not built", pre_act, post_act);
+#undef BAR_GO
   KERNEL_CHECK_RET();
   return MMVQA_OK;
+}
+
+int k_bn_add_relu_fold(hipStream_t st, const float* z, const mmvqa_bn_fold* f3, const float* idn, const mmvqa_bn_fold* fd,
+                       float* out, long rows, int C) {
+  if (!idn) return mmvqa_set_error(MMVQA_ERR_ARG, "bn_add_relu_fold: no identity tensor");
+  return k_bn_act_add_fold(st, z, f3, ACT_NONE, idn, fd, ACT_RELU, out, rows, C);
 }
 
 int k_bn_coef_fwd_keep(hipStream_t st, const double* stat, int C, double count, float eps, const float* gamma,
@@ -1330,14 +1347,17 @@ __global__ void bn_act_add_kernel(const float* __restrict__ z, const float* __re
 // the per-channel statistics are reduced over the 32 pixel lanes in LDS, then one atomic per channel.
 //   forward : z2 = dw(silu(z1*s1+b1)) ; statistics of z2
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ z1, const float* __restrict__ s1,
-                                                        const float* __restrict__ b1, const float* __restrict__ w,
+                                                        const float* __restrict__ b1, const BnFold f1, const float* __restrict__ w,
                                                         float* __restrict__ z2, double* __restrict__ stat, int N,
                                                         int H, int W, int C, int OH, int OW, int stride, int pad) {
   __shared__ double red[256 * 8];
   const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int c = blockIdx.y * 32 + q * 4;
   const long npix = (long)N * OH * OW;
-  f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
+  __shared__ __attribute__((aligned(16))) float cf[2][32];
+  bn_coef_block_fwd<32>(s1, b1, f1, C, blockIdx.y * 32, f1.publish && blockIdx.x == 0, cf);
+  const f32x4 sv = *reinterpret_cast<const f32x4*>(&cf[0][q * 4]), bv = *reinterpret_cast<const f32x4*>(&cf[1][q * 4]);
+  if (f1.stat && f1.publish && f1.nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *f1.nbt += f1.reps;
   f32x4 wv[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -1516,7 +1536,7 @@ __device__ __forceinline__ void dw_reduce_stats(double* red, const double (&sa)[
 }
 
 __global__ __launch_bounds__(256) void dwconv_fwd_tile_kernel(const float* __restrict__ z1, const float* __restrict__ s1,
-                                                             const float* __restrict__ b1, const float* __restrict__ w,
+                                                             const float* __restrict__ b1, const BnFold f1, const float* __restrict__ w,
                                                              float* __restrict__ z2, double* __restrict__ stat, int H,
                                                              int W, int C, int OH, int OW, int stride, int pad) {
   extern __shared__ __attribute__((aligned(16))) float dwsm[];
@@ -1524,7 +1544,10 @@ __global__ __launch_bounds__(256) void dwconv_fwd_tile_kernel(const float* __res
   double* red = reinterpret_cast<double*>(dwsm + (size_t)H * W * 32);       // [256][8]
   const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int n = blockIdx.y, cb = blockIdx.x * 32, c = cb + q * 4;
-  const f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
+  __shared__ __attribute__((aligned(16))) float cf[2][32];   // (folded: the image-0 workgroup of a channel block publishes)
+  bn_coef_block_fwd<32>(s1, b1, f1, C, cb, f1.publish && n == 0, cf);
+  const f32x4 sv = *reinterpret_cast<const f32x4*>(&cf[0][q * 4]), bv = *reinterpret_cast<const f32x4*>(&cf[1][q * 4]);
+  if (f1.stat && f1.publish && f1.nbt && blockIdx.x == 0 && n == 0 && threadIdx.x == 0) *f1.nbt += f1.reps;
   f32x4 wv[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -1694,14 +1717,17 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_tile_kernel(
 // 256-byte segment, the HW pixels are spread over the 16 lanes and reduced through LDS (one thread per image and
 // channel quad walking all HW pixels serially left the chip at 80 waves and 46 us per call: round-2 profile).
 __global__ __launch_bounds__(256) void se_pool_kernel(const float* __restrict__ z, const float* __restrict__ s,
-                                                      const float* __restrict__ b, float* __restrict__ pool, int HW,
+                                                      const float* __restrict__ b, const BnFold f, float* __restrict__ pool, int HW,
                                                       int C) {
   __shared__ f32x4 red[16][17];
   const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int n = blockIdx.y, c = blockIdx.x * 64 + q * 4;
   f32x4 acc = {0, 0, 0, 0};
+  if (f.stat && f.publish && f.nbt && blockIdx.x == 0 && n == 0 && threadIdx.x == 0) *f.nbt += f.reps;
+  __shared__ __attribute__((aligned(16))) float cf[2][64];   // (folded: the image-0 workgroup of a channel block publishes)
+  bn_coef_block_fwd<64>(s, b, f, C, blockIdx.x * 64, f.publish && n == 0, cf);
   if (c < C) {
-    const f32x4 sv = *reinterpret_cast<const f32x4*>(s + c), bv = *reinterpret_cast<const f32x4*>(b + c);
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(&cf[0][q * 4]), bv = *reinterpret_cast<const f32x4*>(&cf[1][q * 4]);
     for (int p = pl; p < HW; p += 16) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(z + ((size_t)n * HW + p) * C + c);
 #pragma unroll
@@ -1830,18 +1856,21 @@ static bool dw_pixel_form() {   // A/B switch: the pixel-strided kernels even wh
 }
 
 int k_dwconv_fwd(hipStream_t st, const float* z1, const float* s1, const float* b1, const float* w, float* z2,
-                 double* stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad) {
+                 double* stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad, const mmvqa_bn_fold* fold) {
   if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
+  if (fold && (!fold->stat || fold->bwd)) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: the fold must be a forward one");
+  mmvqa_bn_fold f1;
+  if (fold) f1 = *fold; else memset(&f1, 0, sizeof(f1));
   const size_t sm = (size_t)H * W * 128 + 256 * 8 * sizeof(double);
   if (sm <= DW_TILE_MAX_BYTES && !dw_pixel_form()) {
     // (every launch: the attribute is per device and the call is cheap -- a once-per-process flag left a second device without it)
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_fwd_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES));
-    hipLaunchKernelGGL(dwconv_fwd_tile_kernel, dim3(C / 32, N), dim3(256), sm, st, z1, s1, b1, w, z2, stat, H, W, C, OH, OW,
+    hipLaunchKernelGGL(dwconv_fwd_tile_kernel, dim3(C / 32, N), dim3(256), sm, st, z1, s1, b1, f1, w, z2, stat, H, W, C, OH, OW,
                        stride, pad);
     KERNEL_CHECK_RET();
     return MMVQA_OK;
   }
-  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(pix_grid((long)N * OH * OW, C / 32), C / 32), dim3(256), 0, st, z1, s1, b1,
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(pix_grid((long)N * OH * OW, C / 32), C / 32), dim3(256), 0, st, z1, s1, b1, f1,
                      w, z2, stat, N, H, W, C, OH, OW, stride, pad);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
@@ -1888,8 +1917,12 @@ int k_dwconv_bwd_weight(hipStream_t st, const float* g2, const float* z2, const 
   return MMVQA_OK;
 }
 
-int k_se_pool(hipStream_t st, const float* z, const float* s, const float* b, float* pool, int N, int HW, int C) {
-  hipLaunchKernelGGL(se_pool_kernel, dim3(cdiv_i(C, 64), N), dim3(256), 0, st, z, s, b, pool, HW, C);
+int k_se_pool(hipStream_t st, const float* z, const float* s, const float* b, float* pool, int N, int HW, int C,
+              const mmvqa_bn_fold* fold) {
+  if (fold && (!fold->stat || fold->bwd || C % 4)) return mmvqa_set_error(MMVQA_ERR_ARG, "se_pool: the fold must be a forward one and C a multiple of 4");
+  mmvqa_bn_fold f;
+  if (fold) f = *fold; else memset(&f, 0, sizeof(f));
+  hipLaunchKernelGGL(se_pool_kernel, dim3(cdiv_i(C, 64), N), dim3(256), 0, st, z, s, b, f, pool, HW, C);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }

@@ -628,6 +628,9 @@ static int bn_coef_bwd(mmvqa_engine* e, hipStream_t st, BNRef& bn) {
 // The ResNet path in training mode folds the BatchNorm coefficients inside the launches that consume them
 // (mmvqa_bn_fold: no coefficient launch between a convolution and its consumer on the dependency chain).
 static inline bool folding(const mmvqa_engine* e) { return e->bn_fold && e->training && e->d.cnn == 0; }
+// The EfficientNet path folds where the FIRST consumer of a BatchNorm is an elementwise kernel (block end, depthwise
+// convolution, squeeze-excite pooling: forward) -- later consumers read what that launch published.
+static inline bool eff_folding(const mmvqa_engine* e) { return e->bn_fold && e->training && e->d.cnn != 0; }
 
 static void set_fold_fwd(mmvqa_engine* e, mmvqa_bn_fold& f, BNRef& bn) {
   memset(&f, 0, sizeof(f));
@@ -1040,7 +1043,7 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
 // --------------------------------------------------------------------------- EfficientNetV2 forward / backward
 // conv (1x1 / 3x3 SAME) whose input is silu(bn_in(x_raw)) [* squeeze-excite gate]; statistics of the output
 static int eff_conv_fwd(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const float* x, const BNRef* bn_in,
-                        const float* gate, int N, int H, int W, int OH, int OW, float* z, BNRef& bn_out) {
+                        const float* gate, int N, int H, int W, int OH, int OW, float* z, BNRef& bn_out, bool coef = true) {
   GemmParams g;
   memset(&g, 0, sizeof(g));
   g.M = N * OH * OW; g.N = c.Cout; g.K = c.KH * c.KH * c.Cin;
@@ -1057,7 +1060,7 @@ static int eff_conv_fwd(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const
   if (e->training) { g.stat1 = stat_ptr(e, bn_out.stat_f); g.stat_bwd = 0; }
   set_sk(e, st, g);
   RUN(PROF_IGEMM, 2.0 * g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 0, 0, st));
-  return bn_coef_fwd(e, st, bn_out);
+  return coef ? bn_coef_fwd(e, st, bn_out) : MMVQA_OK;   // (!coef: the consumer folds the coefficients itself)
 }
 
 static int eff_conv_wgrad(mmvqa_engine* e, hipStream_t st, const ConvRef& c, const float* G, const float* z,
@@ -1088,6 +1091,20 @@ static int effnet_forward(mmvqa_engine* e, hipStream_t st) {
     HIP_CHECK_RET(hipMemsetAsync(stat_ptr(e, 0), 0, e->statzone_floats / 2 * sizeof(float), st));
   HIP_CHECK_RET(hipMemsetAsync(WS(e->vis), 0, (size_t)5 * B * d.hidden * sizeof(float), st));
   const long M0 = (long)B * e->SH * e->SW;
+  const bool fold = eff_folding(e);
+  // out = act(bn(z)) + idn: with folding, this launch derives bn's coefficients from the raw sums and publishes them
+  auto block_end = [&](BNRef& bn, const float* z, int act, const float* idn, float* out, long rows, int C, bool have_coef) -> int {
+    if (fold && !have_coef) {
+      mmvqa_bn_fold f;
+      set_fold_fwd(e, f, bn);
+      RUNB(HB_BN_ACT_ADD, (idn ? 12.0 : 8.0) * rows * C, k_bn_act_add_fold(st, z, &f, act, idn, nullptr, ACT_NONE, out, rows, C));
+    } else {
+      if (!have_coef) TRY(bn_coef_fwd(e, st, bn));
+      RUNB(HB_BN_ACT_ADD, (idn ? 12.0 : 8.0) * rows * C, k_bn_act_add(st, z, WS(bn.scale), WS(bn.shift), act, idn, nullptr, nullptr, 0,
+                                      ACT_NONE, out, rows, C));
+    }
+    return MMVQA_OK;
+  };
   {  // conv_stem 3x3/2 SAME on the NCHW image
     GemmParams g;
     memset(&g, 0, sizeof(g));
@@ -1099,9 +1116,7 @@ static int effnet_forward(mmvqa_engine* e, hipStream_t st) {
     g.C = WS(e->z0); g.c_ld = 24;
     if (e->training) g.stat1 = stat_ptr(e, e->stem_bn.stat_f);
     RUN(PROF_IGEMM, 2.0 * (double)g.M * g.N * g.K, mmvqa_launch_igemm(g, KIND_FWD, 1, 0, st));
-    TRY(bn_coef_fwd(e, st, e->stem_bn));
-    RUNB(HB_BN_ACT_ADD, 8.0 * M0 * 24, k_bn_act_add(st, WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), ACT_SILU, nullptr, nullptr,
-                                    nullptr, 0, ACT_NONE, WS(e->eff_a0), M0, 24));
+    TRY(block_end(e->stem_bn, WS(e->z0), ACT_SILU, nullptr, WS(e->eff_a0), M0, 24, false));
   }
   const float* x = WS(e->eff_a0);
   SideCtx sc(e, st);
@@ -1109,29 +1124,29 @@ static int effnet_forward(mmvqa_engine* e, hipStream_t st) {
     const long Mout = (long)B * b.OH * b.OW;
     const float* idn = b.skip ? x : nullptr;
     if (b.type == 0) {
-      TRY(eff_conv_fwd(e, st, b.c_a, x, nullptr, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.za), b.b_a));
-      RUNB(HB_BN_ACT_ADD, (idn ? 12.0 : 8.0) * Mout * b.cout, k_bn_act_add(st, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), ACT_SILU, idn, nullptr, nullptr, 0,
-                                      ACT_NONE, WS(b.out), Mout, b.cout));
+      TRY(eff_conv_fwd(e, st, b.c_a, x, nullptr, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.za), b.b_a, false));
+      TRY(block_end(b.b_a, WS(b.za), ACT_SILU, idn, WS(b.out), Mout, b.cout, false));
     } else if (b.type == 1) {
       TRY(eff_conv_fwd(e, st, b.c_a, x, nullptr, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.za), b.b_a));
-      TRY(eff_conv_fwd(e, st, b.c_p, WS(b.za), &b.b_a, nullptr, B, b.OH, b.OW, b.OH, b.OW, WS(b.zp), b.b_p));
-      RUNB(HB_BN_ACT_ADD, (idn ? 12.0 : 8.0) * Mout * b.cout, k_bn_act_add(st, WS(b.zp), WS(b.b_p.scale), WS(b.b_p.shift), ACT_NONE, idn, nullptr, nullptr, 0,
-                                      ACT_NONE, WS(b.out), Mout, b.cout));
+      TRY(eff_conv_fwd(e, st, b.c_p, WS(b.za), &b.b_a, nullptr, B, b.OH, b.OW, b.OH, b.OW, WS(b.zp), b.b_p, false));
+      TRY(block_end(b.b_p, WS(b.zp), ACT_NONE, idn, WS(b.out), Mout, b.cout, false));
     } else {
-      TRY(eff_conv_fwd(e, st, b.c_a, x, nullptr, nullptr, B, b.H, b.W, b.H, b.W, WS(b.za), b.b_a));
+      mmvqa_bn_fold fa, fdw;
+      if (fold) { set_fold_fwd(e, fa, b.b_a); set_fold_fwd(e, fdw, b.b_dw); }
+      TRY(eff_conv_fwd(e, st, b.c_a, x, nullptr, nullptr, B, b.H, b.W, b.H, b.W, WS(b.za), b.b_a, !fold));
       RUNB(HB_DWCONV_FWD, 4.0 * ((double)B * b.H * b.W + (double)Mout) * b.mid, k_dwconv_fwd(st, WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), PRM(b.dw_w), WS(b.zdw),
                                       e->training ? stat_ptr(e, b.b_dw.stat_f) : nullptr, B, b.H, b.W, b.mid, b.OH, b.OW,
-                                      b.stride, b.pad));
-      TRY(bn_coef_fwd(e, st, b.b_dw));
+                                      b.stride, b.pad, fold ? &fa : nullptr));
+      if (!fold) TRY(bn_coef_fwd(e, st, b.b_dw));
       // squeeze-excite: gate = sigmoid(W_e silu(W_r mean_hw(a2) + b_r) + b_e)
-      RUNB(HB_SE_POOL, 4.0 * Mout * b.mid, k_se_pool(st, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift), WS(b.pool), B, b.OH * b.OW, b.mid));
+      RUNB(HB_SE_POOL, 4.0 * Mout * b.mid, k_se_pool(st, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift), WS(b.pool), B, b.OH * b.OW, b.mid,
+                                      fold ? &fdw : nullptr));
       RUN(PROF_MATRIX, 2.0 * B * b.mid * b.rd, k_skinny_fwd(st, WS(b.pool), b.mid, PRM(b.se_r.w), PRM(b.se_r.b), ACT_SILU, WS(b.rpre), WS(b.r),
                                       B, b.rd, b.mid));
       RUN(PROF_MATRIX, 2.0 * B * b.mid * b.rd, k_skinny_fwd(st, WS(b.r), b.rd, PRM(b.se_e.w), PRM(b.se_e.b), ACT_SIGMOID, WS(b.gpre),
                                       WS(b.gate), B, b.mid, b.rd));
-      TRY(eff_conv_fwd(e, st, b.c_p, WS(b.zdw), &b.b_dw, WS(b.gate), B, b.OH, b.OW, b.OH, b.OW, WS(b.zp), b.b_p));
-      RUNB(HB_BN_ACT_ADD, (idn ? 12.0 : 8.0) * Mout * b.cout, k_bn_act_add(st, WS(b.zp), WS(b.b_p.scale), WS(b.b_p.shift), ACT_NONE, idn, nullptr, nullptr, 0,
-                                      ACT_NONE, WS(b.out), Mout, b.cout));
+      TRY(eff_conv_fwd(e, st, b.c_p, WS(b.zdw), &b.b_dw, WS(b.gate), B, b.OH, b.OW, b.OH, b.OW, WS(b.zp), b.b_p, false));
+      TRY(block_end(b.b_p, WS(b.zp), ACT_NONE, idn, WS(b.out), Mout, b.cout, false));
     }
     x = WS(b.out);
     // the taps feed only the encoder: side stream, beside the chain of (mostly sub-chip-sized) launches

@@ -32,6 +32,9 @@ int k_bn_coef_bwd(hipStream_t st, const double* stat, int C, double count, const
 int k_bn_add_relu(hipStream_t st, const float* z, const float* s, const float* b, const float* idn,
                   const float* ids, const float* idb, float* out, long rows, int C);
 // relu(bn3(z) + [bnd](idn)) with the BatchNorm coefficients folded from raw sums inside the kernel (fd == NULL: plain identity)
+// out = post(pre(bn(z)) + [bn_d](idn)) with the BatchNorm coefficients folded from raw sums in the kernel (idn may be null)
+int k_bn_act_add_fold(hipStream_t st, const float* z, const mmvqa_bn_fold* f3, int pre_act, const float* idn,
+                      const mmvqa_bn_fold* fd, int post_act, float* out, long rows, int C);
 int k_bn_add_relu_fold(hipStream_t st, const float* z, const mmvqa_bn_fold* f3, const float* idn, const mmvqa_bn_fold* fd,
                        float* out, long rows, int C);
 int k_maxpool_fwd(hipStream_t st, const float* z, const float* s, const float* b, float* out, unsigned char* idx,
@@ -76,7 +79,7 @@ int k_dropout_copy(hipStream_t st, const float* x, float* y, long n, float p, ui
 int k_bn_act_add(hipStream_t st, const float* z, const float* s, const float* b, int pre_act, const float* idn,
                  const float* ids, const float* idb, int idn_act, int post_act, float* out, long rows, int C);
 int k_dwconv_fwd(hipStream_t st, const float* z1, const float* s1, const float* b1, const float* w, float* z2,
-                 double* stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad);
+                 double* stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad, const mmvqa_bn_fold* fold = nullptr);
 int k_dwconv_bwd_data(hipStream_t st, const float* g2, const float* z2, const float* P, const float* Q,
                       const float* R, const float* w, const float* z1, const float* s1, const float* b1,
                       const float* mean1, const float* invstd1, float* g1, double* stat, int N, int H, int W, int C,
@@ -84,7 +87,8 @@ int k_dwconv_bwd_data(hipStream_t st, const float* g2, const float* z2, const fl
 int k_dwconv_bwd_weight(hipStream_t st, const float* g2, const float* z2, const float* P, const float* Q,
                         const float* R, const float* z1, const float* s1, const float* b1, float* dw, int N, int H,
                         int W, int C, int OH, int OW, int stride, int pad);
-int k_se_pool(hipStream_t st, const float* z, const float* s, const float* b, float* pool, int N, int HW, int C);
+int k_se_pool(hipStream_t st, const float* z, const float* s, const float* b, float* pool, int N, int HW, int C,
+              const mmvqa_bn_fold* fold = nullptr);
 int k_se_dgate(hipStream_t st, const float* t, const float* z, const float* s, const float* b, float* dgate, int N,
                int HW, int C, float* zero = nullptr, int nzero = 0);
 int k_act_bwd_stats(hipStream_t st, const float* t, const float* gate, const float* add, const float* z,
