@@ -206,6 +206,24 @@ __device__ __forceinline__ void bn_fold_bwd(const BnFold& f, int C, int c, bool 
   }
 }
 
+// the same for the backward coefficients (dz = P*g + Q*z + R) of a workgroup's NCH channels; ends with a barrier
+template <int NCH>
+__device__ __forceinline__ void bn_coef_block_bwd(const float* __restrict__ P, const float* __restrict__ Q,
+                                                  const float* __restrict__ R, const BnFold& f, int C, int c0, bool pub,
+                                                  float (*cf)[NCH]) {
+  const int t = threadIdx.x;
+  if (t < NCH) {
+    float p = 0.f, q = 0.f, r = 0.f;
+    const int c = c0 + t;
+    if (c < C) {
+      if (f.stat) bn_fold_bwd(f, C, c, pub, p, q, r);
+      else { p = P[c]; q = Q[c]; r = R[c]; }
+    }
+    cf[0][t] = p; cf[1][t] = q; cf[2][t] = r;
+  }
+  __syncthreads();
+}
+
 // --------------------------------------------------------------------------- host side
 int mmvqa_set_error(int code, const char* fmt, ...);
 #define MMVQA_OK 0

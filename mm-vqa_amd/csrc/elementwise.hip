@@ -1406,15 +1406,18 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(
     const float* __restrict__ g2, const float* __restrict__ z2, const float* __restrict__ P, const float* __restrict__ Q,
     const float* __restrict__ R, const float* __restrict__ w, const float* __restrict__ z1, const float* __restrict__ s1,
     const float* __restrict__ b1, const float* __restrict__ mean1, const float* __restrict__ invstd1,
-    float* __restrict__ g1, double* __restrict__ stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad) {
+    float* __restrict__ g1, double* __restrict__ stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad,
+    const BnFold f2) {
   __shared__ double red[256 * 8];
+  __shared__ __attribute__((aligned(16))) float cf[3][32];
   const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int c = blockIdx.y * 32 + q * 4;
   const long npix = (long)N * H * W;
+  bn_coef_block_bwd<32>(P, Q, R, f2, C, blockIdx.y * 32, f2.publish && blockIdx.x == 0, cf);
   f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
   f32x4 mu = *reinterpret_cast<const f32x4*>(mean1 + c), is = *reinterpret_cast<const f32x4*>(invstd1 + c);
-  f32x4 Pv = *reinterpret_cast<const f32x4*>(P + c), Qv = *reinterpret_cast<const f32x4*>(Q + c),
-        Rv = *reinterpret_cast<const f32x4*>(R + c);
+  f32x4 Pv = *reinterpret_cast<const f32x4*>(&cf[0][q * 4]), Qv = *reinterpret_cast<const f32x4*>(&cf[1][q * 4]),
+        Rv = *reinterpret_cast<const f32x4*>(&cf[2][q * 4]);
   f32x4 wv[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -1470,14 +1473,16 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(
     const float* __restrict__ g2, const float* __restrict__ z2, const float* __restrict__ P, const float* __restrict__ Q,
     const float* __restrict__ R, const float* __restrict__ z1, const float* __restrict__ s1, const float* __restrict__ b1,
-    float* __restrict__ dw, int N, int H, int W, int C, int OH, int OW, int stride, int pad) {
+    float* __restrict__ dw, int N, int H, int W, int C, int OH, int OW, int stride, int pad, const BnFold f2) {
   __shared__ float red[32 * 8 * 36];
+  __shared__ __attribute__((aligned(16))) float cf[3][32];
   const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int c = blockIdx.y * 32 + q * 4;
   const long npix = (long)N * OH * OW;
+  bn_coef_block_bwd<32>(P, Q, R, f2, C, blockIdx.y * 32, false, cf);   // (the data gradient publishes)
   f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
-  f32x4 Pv = *reinterpret_cast<const f32x4*>(P + c), Qv = *reinterpret_cast<const f32x4*>(Q + c),
-        Rv = *reinterpret_cast<const f32x4*>(R + c);
+  f32x4 Pv = *reinterpret_cast<const f32x4*>(&cf[0][q * 4]), Qv = *reinterpret_cast<const f32x4*>(&cf[1][q * 4]),
+        Rv = *reinterpret_cast<const f32x4*>(&cf[2][q * 4]);
   f32x4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = f32x4{0, 0, 0, 0};
@@ -1591,16 +1596,19 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_tile_kernel(
     const float* __restrict__ g2, const float* __restrict__ z2, const float* __restrict__ P, const float* __restrict__ Q,
     const float* __restrict__ R, const float* __restrict__ w, const float* __restrict__ z1, const float* __restrict__ s1,
     const float* __restrict__ b1, const float* __restrict__ mean1, const float* __restrict__ invstd1,
-    float* __restrict__ g1, double* __restrict__ stat, int H, int W, int C, int OH, int OW, int stride, int pad) {
+    float* __restrict__ g1, double* __restrict__ stat, int H, int W, int C, int OH, int OW, int stride, int pad,
+    const BnFold f2) {
   extern __shared__ __attribute__((aligned(16))) float dwsm[];
+  __shared__ __attribute__((aligned(16))) float cf[3][32];
   f32x4* dzs = reinterpret_cast<f32x4*>(dwsm);                              // [OH*OW][8]  dz2 = P*g2 + Q*z2 + R
   double* red = reinterpret_cast<double*>(dwsm + (size_t)OH * OW * 32);
   const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int n = blockIdx.y, cb = blockIdx.x * 32, c = cb + q * 4;
+  bn_coef_block_bwd<32>(P, Q, R, f2, C, cb, f2.publish && n == 0, cf);   // (folded: the image-0 workgroup of a channel block publishes)
   const f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
   const f32x4 mu = *reinterpret_cast<const f32x4*>(mean1 + c), is = *reinterpret_cast<const f32x4*>(invstd1 + c);
-  const f32x4 Pv = *reinterpret_cast<const f32x4*>(P + c), Qv = *reinterpret_cast<const f32x4*>(Q + c),
-              Rv = *reinterpret_cast<const f32x4*>(R + c);
+  const f32x4 Pv = *reinterpret_cast<const f32x4*>(&cf[0][q * 4]), Qv = *reinterpret_cast<const f32x4*>(&cf[1][q * 4]),
+              Rv = *reinterpret_cast<const f32x4*>(&cf[2][q * 4]);
   f32x4 wv[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -1653,16 +1661,18 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_tile_kernel(
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_tile_kernel(
     const float* __restrict__ g2, const float* __restrict__ z2, const float* __restrict__ P, const float* __restrict__ Q,
     const float* __restrict__ R, const float* __restrict__ z1, const float* __restrict__ s1, const float* __restrict__ b1,
-    float* __restrict__ dw, int H, int W, int C, int OH, int OW, int stride, int pad) {
+    float* __restrict__ dw, int H, int W, int C, int OH, int OW, int stride, int pad, const BnFold f2) {
   extern __shared__ __attribute__((aligned(16))) float dwsm[];
+  __shared__ __attribute__((aligned(16))) float cf[3][32];
   f32x4* act = reinterpret_cast<f32x4*>(dwsm);                              // [H*W][8]
   f32x4* dzs = act + (size_t)H * W * 8;                                     // [OH*OW][8]
   float* red = dwsm + ((size_t)H * W + (size_t)OH * OW) * 32;               // [32*8][36]
   const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int n = blockIdx.y, cb = blockIdx.x * 32, c = cb + q * 4;
+  bn_coef_block_bwd<32>(P, Q, R, f2, C, cb, false, cf);   // (the data gradient publishes)
   const f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + c), bv = *reinterpret_cast<const f32x4*>(b1 + c);
-  const f32x4 Pv = *reinterpret_cast<const f32x4*>(P + c), Qv = *reinterpret_cast<const f32x4*>(Q + c),
-              Rv = *reinterpret_cast<const f32x4*>(R + c);
+  const f32x4 Pv = *reinterpret_cast<const f32x4*>(&cf[0][q * 4]), Qv = *reinterpret_cast<const f32x4*>(&cf[1][q * 4]),
+              Rv = *reinterpret_cast<const f32x4*>(&cf[2][q * 4]);
   const size_t ib = (size_t)n * H * W * C + c, ob = (size_t)n * OH * OW * C + c;
   for (int p = pl; p < H * W; p += 32) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(z1 + ib + (size_t)p * C);
@@ -1879,40 +1889,46 @@ int k_dwconv_fwd(hipStream_t st, const float* z1, const float* s1, const float* 
 int k_dwconv_bwd_data(hipStream_t st, const float* g2, const float* z2, const float* P, const float* Q,
                       const float* R, const float* w, const float* z1, const float* s1, const float* b1,
                       const float* mean1, const float* invstd1, float* g1, double* stat, int N, int H, int W, int C,
-                      int OH, int OW, int stride, int pad) {
+                      int OH, int OW, int stride, int pad, const mmvqa_bn_fold* fold) {
   if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
+  if (fold && (!fold->stat || !fold->bwd)) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv_bwd_data: the fold must be a backward one");
+  mmvqa_bn_fold f2;
+  if (fold) f2 = *fold; else memset(&f2, 0, sizeof(f2));
   const size_t sm = (size_t)OH * OW * 128 + 256 * 8 * sizeof(double);
   if (sm <= DW_TILE_MAX_BYTES && !dw_pixel_form()) {
     // (every launch: the attribute is per device and the call is cheap -- a once-per-process flag left a second device without it)
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_bwd_data_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES));
     hipLaunchKernelGGL(dwconv_bwd_data_tile_kernel, dim3(C / 32, N), dim3(256), sm, st, g2, z2, P, Q, R, w, z1, s1, b1,
-                       mean1, invstd1, g1, stat, H, W, C, OH, OW, stride, pad);
+                       mean1, invstd1, g1, stat, H, W, C, OH, OW, stride, pad, f2);
     KERNEL_CHECK_RET();
     return MMVQA_OK;
   }
   hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(pix_grid((long)N * H * W, C / 32), C / 32), dim3(256), 0, st, g2, z2,
-                     P, Q, R, w, z1, s1, b1, mean1, invstd1, g1, stat, N, H, W, C, OH, OW, stride, pad);
+                     P, Q, R, w, z1, s1, b1, mean1, invstd1, g1, stat, N, H, W, C, OH, OW, stride, pad, f2);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }
 
 int k_dwconv_bwd_weight(hipStream_t st, const float* g2, const float* z2, const float* P, const float* Q,
                         const float* R, const float* z1, const float* s1, const float* b1, float* dw, int N, int H,
-                        int W, int C, int OH, int OW, int stride, int pad) {
+                        int W, int C, int OH, int OW, int stride, int pad, const mmvqa_bn_fold* fold) {
   if (C % 32) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv: C=%d must be a multiple of 32", C);
+  if (fold && (!fold->stat || !fold->bwd)) return mmvqa_set_error(MMVQA_ERR_ARG, "dwconv_bwd_weight: the fold must be a backward one");
+  mmvqa_bn_fold f2;
+  if (fold) f2 = *fold; else memset(&f2, 0, sizeof(f2));
   const size_t sm = ((size_t)H * W + (size_t)OH * OW) * 128 + 32 * 8 * 36 * sizeof(float);
   if (sm <= DW_TILE_MAX_BYTES && !dw_pixel_form()) {
     // (every launch: the attribute is per device and the call is cheap -- a once-per-process flag left a second device without it)
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)dwconv_bwd_weight_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DW_TILE_MAX_BYTES));
     hipLaunchKernelGGL(dwconv_bwd_weight_tile_kernel, dim3(C / 32, N), dim3(256), sm, st, g2, z2, P, Q, R, z1, s1, b1, dw, H, W,
-                       C, OH, OW, stride, pad);
+                       C, OH, OW, stride, pad, f2);
     KERNEL_CHECK_RET();
     return MMVQA_OK;
   }
   int g = pix_grid((long)N * OH * OW, C / 32);
   if (g > 64) g = 64;   // every workgroup ends with 288 atomics per 32 channels
   hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3(g, C / 32), dim3(256), 0, st, g2, z2, P, Q, R, z1, s1, b1, dw, N,
-                     H, W, C, OH, OW, stride, pad);
+                     H, W, C, OH, OW, stride, pad, f2);
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }

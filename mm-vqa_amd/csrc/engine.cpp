@@ -1161,6 +1161,11 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
   HIP_CHECK_RET(hipMemsetAsync(stat_ptr(e, 0) + e->statzone_floats / 4, 0,
                                e->statzone_floats / 2 * sizeof(float), st));
   const int nb = (int)e->eff.size();
+  // BatchNorm-backward coefficients folded where both consumers are elementwise kernels (the depthwise BatchNorm).  Folding
+  // in the convolutions' weight / data gradients as the ResNet path does was measured and dropped here: these BatchNorms
+  // keep 16 replicas of their sums and have up to 3072 channels, every workgroup of a data gradient folds all of them, and
+  // the step got 0.2 ms slower than with the coefficient launches (config 3, same box).
+  const bool fold = eff_folding(e);
   // Weight gradients (convolutions, depthwise, taps) only feed the optimizer: they run on the side stream beside the
   // data-gradient chain, whose launches are mostly smaller than the chip.  A side launch starts after everything the
   // caller's stream had queued when it was issued (fork) and leaves an event behind; the chain waits for that event before
@@ -1240,18 +1245,20 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
       RUNB(HB_ACT_BWD_STATS, 12.0 * Mout * b.mid, k_act_bwd_stats(st, gA, WS(b.gate), dpool, WS(b.zdw), WS(b.b_dw.scale), WS(b.b_dw.shift),
                                          WS(b.b_dw.mean), WS(b.b_dw.invstd), ACT_SILU, gB, stat_ptr(e, b.b_dw.stat_b), Mout,
                                          b.OH * b.OW, b.mid));
-      TRY(bn_coef_bwd(e, st, b.b_dw));
+      mmvqa_bn_fold fdw_w, fdw_d;
+      if (fold) { set_fold_bwd(e, fdw_w, b.b_dw, false); set_fold_bwd(e, fdw_d, b.b_dw, true); }
+      else TRY(bn_coef_bwd(e, st, b.b_dw));
       scx.fork();
       {
         hipStream_t st = sd;   // (RUNB times / launches on `st`)
         RUNB(HB_DWCONV_BWD_WEIGHT, 4.0 * (2.0 * Mout + (double)Min) * b.mid, k_dwconv_bwd_weight(st, gB, WS(b.zdw), WS(b.b_dw.P), WS(b.b_dw.Q), WS(b.b_dw.R), WS(b.za),
                                              WS(b.b_a.scale), WS(b.b_a.shift), GRD(b.dw_w), B, b.H, b.W, b.mid, b.OH, b.OW,
-                                             b.stride, b.pad));
+                                             b.stride, b.pad, fold ? &fdw_w : nullptr));
       }
       ev_gB[pi] = scx.mark();
       RUNB(HB_DWCONV_BWD_DATA, 4.0 * (2.0 * Mout + 2.0 * (double)Min) * b.mid, k_dwconv_bwd_data(st, gB, WS(b.zdw), WS(b.b_dw.P), WS(b.b_dw.Q), WS(b.b_dw.R), PRM(b.dw_w),
                                            WS(b.za), WS(b.b_a.scale), WS(b.b_a.shift), WS(b.b_a.mean), WS(b.b_a.invstd), gA,
-                                           stat_ptr(e, b.b_a.stat_b), B, b.H, b.W, b.mid, b.OH, b.OW, b.stride, b.pad));
+                                           stat_ptr(e, b.b_a.stat_b), B, b.H, b.W, b.mid, b.OH, b.OW, b.stride, b.pad, fold ? &fdw_d : nullptr));
       dz_first = gA;
     }
     // first convolution of the block: weight gradient, then the gradient wrt the block input

@@ -83,10 +83,10 @@ int k_dwconv_fwd(hipStream_t st, const float* z1, const float* s1, const float* 
 int k_dwconv_bwd_data(hipStream_t st, const float* g2, const float* z2, const float* P, const float* Q,
                       const float* R, const float* w, const float* z1, const float* s1, const float* b1,
                       const float* mean1, const float* invstd1, float* g1, double* stat, int N, int H, int W, int C,
-                      int OH, int OW, int stride, int pad);
+                      int OH, int OW, int stride, int pad, const mmvqa_bn_fold* fold = nullptr);
 int k_dwconv_bwd_weight(hipStream_t st, const float* g2, const float* z2, const float* P, const float* Q,
                         const float* R, const float* z1, const float* s1, const float* b1, float* dw, int N, int H,
-                        int W, int C, int OH, int OW, int stride, int pad);
+                        int W, int C, int OH, int OW, int stride, int pad, const mmvqa_bn_fold* fold = nullptr);
 int k_se_pool(hipStream_t st, const float* z, const float* s, const float* b, float* pool, int N, int HW, int C,
               const mmvqa_bn_fold* fold = nullptr);
 int k_se_dgate(hipStream_t st, const float* t, const float* z, const float* s, const float* b, float* dgate, int N,
