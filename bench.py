@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--nccl-algo", type=str, default=None, help="NCCL_ALGO for RCCL (e.g. Ring, Tree)")
     ap.add_argument("--nccl-proto", type=str, default=None, help="NCCL_PROTO (e.g. Simple, LL, LL128)")
     ap.add_argument("--nccl-min-nchannels", type=int, default=None, help="NCCL_MIN_NCHANNELS: more channels use more xGMI links at once")
+    ap.add_argument("--overlap-adam", action="store_true",
+                    help="A/B switch: Adam per finished gradient range beside the backward pass instead of one launch after it "
+                         "(measured time-neutral on configs 2 and 3: DESIGN 7.4)")
     ap.add_argument("--native-comm", action="store_true",
                     help="gradient all-reduce through include/mmvqa_comm.h (mmvqa_allreduce_bucket on an own RCCL communicator and "
                          "stream) instead of torch.distributed.all_reduce")
@@ -245,6 +248,9 @@ def main():
     if world > 1:
         # all-reduce of finished gradient ranges overlaps the backbone backward; `ready` orders RCCL's stream explicitly
         model.set_grad_ready_hook(red.start, with_event=True)
+    if a.overlap_adam:
+        # Adam of a finished (and, for N > 1, all-reduced) gradient range runs beside the rest of the backward pass
+        opt.overlap_backward(red, grad_scale=1.0 / world)
     if CONFIG == 4:
         from mmvqa_amd import train as TR
         va = synth.roco_batch(B_PER_GPU // 2, T, HW, VOCAB, seed=1234 + rank, device=dev)

@@ -1257,7 +1257,11 @@ int k_adam(hipStream_t st, float* p, float* g, float* m, float* v, long n, doubl
   if (n % 4 != 0) return mmvqa_set_error(MMVQA_ERR_ARG, "adam: n must be a multiple of 4");
   // bias corrections and (1 - beta) in double, as torch.optim.Adam computes them from Python floats
   const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, st, p, g, m, v, n / 4,
+  // MMVQA_ADAM_WGS: cap on the workgroups of one launch (A/B: a ranged launch beside the backward pass takes wave slots
+  // and bandwidth from the GEMMs it shares the chip with)
+  const char* cap_s = getenv("MMVQA_ADAM_WGS");
+  const int cap = cap_s ? atoi(cap_s) : 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, cap > 0 ? cap : 4096)), dim3(256), 0, st, p, g, m, v, n / 4,
                      (float)(lr / bc1), (float)b1, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps,
                      (float)sqrt(bc2), gscale, zero_grad);
   KERNEL_CHECK_RET();

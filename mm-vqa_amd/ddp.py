@@ -108,6 +108,11 @@ class GradReducer:
             hi = lo
         self.pending = []
         self.launched = 0
+        self.after_bucket = None    # optim.FusedAdam.overlap_backward(): called per exchanged range with its work / stream
+
+    def exchanges(self):
+        """does start() exchange anything (else it only orders the stream)"""
+        return world() > 1 or self.native is not None
 
     def start(self, lo=0, hi=None, ready=None):
         """launch async all-reduce (SUM) of every bucket inside [lo, hi).  This is the gradient-ready hook of
@@ -135,13 +140,18 @@ class GradReducer:
                 a2, b2 = max(a, lo), min(b, hi)
                 if a2 < b2:
                     self.native.allreduce(self.flat[a2:b2], stream=self.comm_stream)
+                    if self.after_bucket is not None:
+                        self.after_bucket(a2, b2, stream=self.comm_stream)
             self.native_pending = True
             self.launched += max(0, hi - lo)
             return
         for a, b in self.buckets:
             a2, b2 = max(a, lo), min(b, hi)
             if a2 < b2:
-                self.pending.append(dist.all_reduce(self.flat[a2:b2], op=dist.ReduceOp.SUM, async_op=True))
+                w = dist.all_reduce(self.flat[a2:b2], op=dist.ReduceOp.SUM, async_op=True)
+                self.pending.append(w)
+                if self.after_bucket is not None:
+                    self.after_bucket(a2, b2, work=w)
         self.launched += max(0, hi - lo)
 
     def finish(self):

@@ -65,6 +65,7 @@ def common_args(p):
     p.add_argument("--resnet_width", type=int, default=64)
     p.add_argument("--emb_vocab", type=int, default=30522)
     p.add_argument("--bucket_mb", type=float, default=64.0, help="all-reduce bucket size (data parallel)")
+    p.add_argument("--overlap_adam", action="store_true", help="Adam per finished gradient range beside the backward pass (measured time-neutral; not with --clip)")
 
 
 class Ctx:
@@ -121,6 +122,10 @@ def build(args, ctx, n_classes=None):
         model.set_grad_ready_hook(red.start, with_event=True)
         if ctx.rank == 0:
             print(f"data parallel: {comm_info(red)} replica checksum {cs}", flush=True)
+    # opt-in: Adam per finished (all-reduced) gradient range, beside the rest of the backward pass -- not with gradient
+    # clipping, which needs the norm of the WHOLE gradient before the first update (vqamed2019/utils.py:663-664)
+    if getattr(args, "overlap_adam", False) and not getattr(args, "clip", False):
+        opt.overlap_backward(red, grad_scale=1.0 / ctx.world)
     return model, opt, sched, red
 
 

@@ -517,6 +517,57 @@ def test_stock_torch_adam_steps_the_flat_buffer():
         assert off <= 0.01, f"{n}: {off:.3f} of the elements differ between FusedAdam and torch.optim.Adam after two steps"
 
 
+@pytest.mark.parametrize("cnn", ["resnet152", "tf_efficientnetv2_m"])
+def test_adam_beside_the_backward_pass(cnn):
+    """FusedAdam.overlap_backward(): the update of a gradient range is enqueued from backward's announcement of it, on a
+    stream of its own.  (1) The announcements of one backward partition the flat buffer, every range is updated exactly
+    once and step() has nothing left; (2) driven by hand on FIXED gradients the ranged launches give bit-identical
+    parameters / moments to the one-launch form, incl. a range nobody announced; (3) three training steps land where
+    the one-launch optimizer lands (the float atomics of the weight gradients differ run to run, hence a tolerance)."""
+    kw = dict(cnn_encoder=cnn, effnet_depth_div=8) if cnn != "resnet152" else {}
+    args = mini_args(**kw)
+    _, a = build_pair(args, seed=11)
+    _, b = build_pair(args, seed=11)
+    a.train(), b.train()
+    lr = 1e-3
+    opt_a, opt_b = mmvqa_amd.FusedAdam(a, lr=lr), mmvqa_amd.FusedAdam(b, lr=lr)
+    n = b.flat_params.numel()
+    # (2) by hand: same gradients, ranged vs one launch
+    g = torch.randn(n, device=dev())
+    a.flat_grads.copy_(g), b.flat_grads.copy_(g)
+    opt_b.overlap_backward()
+    ev = torch.cuda.Event()
+    ev.record()
+    cuts = [0, 4 * (n // 12), 4 * (n // 7), 4 * (n // 5), n - 4 * (n // 9), n]   # [cuts[3], cuts[4]) is never announced
+    for lo, hi in ((cuts[4], cuts[5]), (cuts[0], cuts[1]), (cuts[2], cuts[3]), (cuts[1], cuts[2])):
+        opt_b._on_ready(lo, hi, ev)
+    opt_a.step(), opt_b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(a.flat_params, b.flat_params) and torch.equal(opt_a.m, opt_b.m) and torch.equal(opt_a.v, opt_b.v)
+    assert float(b.flat_grads.abs().max()) == 0.0 and opt_b._done == []
+    # (1) + (3) in the loop
+    seen = []
+    early = opt_b._early
+    opt_b._early = lambda lo, hi, **k: (seen.append((lo, hi)), early(lo, hi, **k))[1]
+    batches = [tuple(t.to(dev()) for t in synth.roco_batch(3, 12, 32, vocab=50, seed=40 + i, mlm_prob=0.3)) for i in range(3)]
+    for img, ids, seg, mask, tgt in batches:
+        for m, o in ((a, opt_a), (b, opt_b)):
+            o.zero_grad()
+            mmvqa_amd.mlm_loss(m(img, ids, seg, mask), tgt)[0].backward()
+            if o is opt_b:
+                assert sorted(opt_b._done) == sorted(seen[-len(opt_b._done):]) and sum(h - l for l, h in opt_b._done) == n
+                pos = 0
+                for lo, hi in sorted(opt_b._done):
+                    assert lo == pos, (lo, pos)
+                    pos = hi
+            o.step()
+    torch.cuda.synchronize()
+    assert len(seen) >= 3 * 3
+    assert float(b.flat_grads.abs().max()) == 0.0
+    off = ((a.flat_params - b.flat_params).abs() > 0.05 * lr).float().mean().item()
+    assert off <= 0.01, f"{off:.4f} of the parameters differ between the two forms after three steps"
+
+
 def test_dropout_training_mode():
     args = mini_args(hidden_dropout_prob=0.3, emb_dropout_prob=0.1)
     _, hip = build_pair(args, seed=5)
