@@ -298,6 +298,25 @@ int mmvqa_dwconv_bwd_weight(mmvqa_stream_t s, const float* g2, const float* z2, 
 int mmvqa_se_pool(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, float* pool, int N, int HW, int C);
 int mmvqa_se_dgate(mmvqa_stream_t s, const float* t, const float* z, const float* sc, const float* sh, float* dgate,
                    int N, int HW, int C);
+/* The same launches with the BatchNorm coefficients of their operand folded from the producer's raw sums inside the
+ * launch (mmvqa_bn_fold; round 3): the FIRST consumer of a train-mode BatchNorm needs no coefficient launch in front.
+ * Each workgroup derives the coefficients of its 32 / 64 channels once into LDS; with fold->publish the image-0
+ * workgroup of a channel block writes what the coefficient launch would have (scale / shift / mean / invstd / running
+ * statistics with the k-fold rule / batch counter; backward: P, Q, R and dgamma, dbeta) for the later consumers.
+ * forward folds: (s1, b1) / (sc, sh) are ignored; backward folds (bwd_data publishes, bwd_weight never): (P, Q, R) are.
+ * fold == NULL: identical to the plain entry.  (timm MBConv: conv_pw -> bn1 -> SiLU -> conv_dw -> bn2 -> SiLU -> SE) */
+int mmvqa_dwconv_fwd_fold(mmvqa_stream_t s, const float* z1, const float* s1, const float* b1, const float* w, float* z2,
+                          double* stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad,
+                          const mmvqa_bn_fold* fold);
+int mmvqa_dwconv_bwd_data_fold(mmvqa_stream_t s, const float* g2, const float* z2, const float* P, const float* Q,
+                               const float* R, const float* w, const float* z1, const float* s1, const float* b1,
+                               const float* mean1, const float* invstd1, float* g1, double* stat, int N, int H, int W,
+                               int C, int OH, int OW, int stride, int pad, const mmvqa_bn_fold* fold);
+int mmvqa_dwconv_bwd_weight_fold(mmvqa_stream_t s, const float* g2, const float* z2, const float* P, const float* Q,
+                                 const float* R, const float* z1, const float* s1, const float* b1, float* dw, int N,
+                                 int H, int W, int C, int OH, int OW, int stride, int pad, const mmvqa_bn_fold* fold);
+int mmvqa_se_pool_fold(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, float* pool, int N, int HW,
+                       int C, const mmvqa_bn_fold* fold);
 /* visual-token tap of a feature map with few channels (models/image_encoding.py:53-62 at the stem: conv1x1 C -> N,
  * activation, global average pool): out[img][n] += mean_hw act(sum_c x'[pix][c] W[n][c]) with x' = x, or
  * relu(x*sc+sh) when sc/sh are given; x [M, C] NHWC rows, M = images*HW.  C in {24, 64}, M and HW multiples of 32,
@@ -326,6 +345,10 @@ int mmvqa_act_bwd_stats(mmvqa_stream_t s, const float* t, const float* gate, con
 /* block end: out = post(pre(z*sc+sh) + idn'), idn' = idn | iact(idn*ids+idb) | nothing */
 int mmvqa_bn_act_add(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, int pre_act, const float* idn,
                      const float* ids, const float* idb, int idn_act, int post_act, float* out, long rows, int C);
+/* the block end with folded coefficients: out = post(pre(bn(z)) + [bn_d](idn)); idn / fd nullable; (pre, post) in
+ * {(NONE, RELU): ResNet Bottleneck = mmvqa_bn_add_relu_fold, (SILU, NONE) and (NONE, NONE): EfficientNetV2 blocks} */
+int mmvqa_bn_act_add_fold(mmvqa_stream_t s, const float* z, const mmvqa_bn_fold* f3, int pre_act, const float* idn,
+                          const mmvqa_bn_fold* fd, int post_act, float* out, long rows, int C);
 /* torch.optim.Adam defaults over a flat buffer; g is scaled by gscale first and zeroed when zero_grad != 0 */
 int mmvqa_adam(mmvqa_stream_t s, float* p, float* g, float* m, float* v, long n, double lr, double b1, double b2,
                double eps, int step, float gscale, int zero_grad);

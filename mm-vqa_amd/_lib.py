@@ -126,6 +126,11 @@ SIGNATURES = {
     "mmvqa_dwconv_bwd_data": (_i, [_P] * 14 + [_i] * 8),
     "mmvqa_dwconv_bwd_weight": (_i, [_P] * 10 + [_i] * 8),
     "mmvqa_se_pool": (_i, [_P, _P, _P, _P, _P, _i, _i, _i]),
+    "mmvqa_dwconv_fwd_fold": (_i, [_P, _P, _P, _P, _P, _P, _P] + [_i] * 8 + [C.POINTER(BnFold)]),
+    "mmvqa_dwconv_bwd_data_fold": (_i, [_P] * 14 + [_i] * 8 + [C.POINTER(BnFold)]),
+    "mmvqa_dwconv_bwd_weight_fold": (_i, [_P] * 10 + [_i] * 8 + [C.POINTER(BnFold)]),
+    "mmvqa_se_pool_fold": (_i, [_P, _P, _P, _P, _P, _i, _i, _i, C.POINTER(BnFold)]),
+    "mmvqa_bn_act_add_fold": (_i, [_P, _P, C.POINTER(BnFold), _i, _P, C.POINTER(BnFold), _i, _P, _l, _i]),
     "mmvqa_se_dgate": (_i, [_P, _P, _P, _P, _P, _P, _i, _i, _i]),
     "mmvqa_tap_thin_ok": (_i, [_l, _i, _i, _i]),
     "mmvqa_tap_thin_fwd": (_i, [_P] * 6 + [_l, _i, _i, _i, _i]),

@@ -168,6 +168,30 @@ int mmvqa_dwconv_bwd_weight(mmvqa_stream_t s, const float* g2, const float* z2, 
 int mmvqa_se_pool(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, float* pool, int N, int HW, int C) {
   return k_se_pool(ST(s), z, sc, sh, pool, N, HW, C);
 }
+int mmvqa_dwconv_fwd_fold(mmvqa_stream_t s, const float* z1, const float* s1, const float* b1, const float* w, float* z2,
+                          double* stat, int N, int H, int W, int C, int OH, int OW, int stride, int pad,
+                          const mmvqa_bn_fold* fold) {
+  return k_dwconv_fwd(ST(s), z1, s1, b1, w, z2, stat, N, H, W, C, OH, OW, stride, pad, fold);
+}
+int mmvqa_dwconv_bwd_data_fold(mmvqa_stream_t s, const float* g2, const float* z2, const float* P, const float* Q,
+                               const float* R, const float* w, const float* z1, const float* s1, const float* b1,
+                               const float* mean1, const float* invstd1, float* g1, double* stat, int N, int H, int W,
+                               int C, int OH, int OW, int stride, int pad, const mmvqa_bn_fold* fold) {
+  return k_dwconv_bwd_data(ST(s), g2, z2, P, Q, R, w, z1, s1, b1, mean1, invstd1, g1, stat, N, H, W, C, OH, OW, stride, pad, fold);
+}
+int mmvqa_dwconv_bwd_weight_fold(mmvqa_stream_t s, const float* g2, const float* z2, const float* P, const float* Q,
+                                 const float* R, const float* z1, const float* s1, const float* b1, float* dw, int N,
+                                 int H, int W, int C, int OH, int OW, int stride, int pad, const mmvqa_bn_fold* fold) {
+  return k_dwconv_bwd_weight(ST(s), g2, z2, P, Q, R, z1, s1, b1, dw, N, H, W, C, OH, OW, stride, pad, fold);
+}
+int mmvqa_se_pool_fold(mmvqa_stream_t s, const float* z, const float* sc, const float* sh, float* pool, int N, int HW,
+                       int C, const mmvqa_bn_fold* fold) {
+  return k_se_pool(ST(s), z, sc, sh, pool, N, HW, C, fold);
+}
+int mmvqa_bn_act_add_fold(mmvqa_stream_t s, const float* z, const mmvqa_bn_fold* f3, int pre_act, const float* idn,
+                          const mmvqa_bn_fold* fd, int post_act, float* out, long rows, int C) {
+  return k_bn_act_add_fold(ST(s), z, f3, pre_act, idn, fd, post_act, out, rows, C);
+}
 int mmvqa_se_dgate(mmvqa_stream_t s, const float* t, const float* z, const float* sc, const float* sh, float* dgate,
                    int N, int HW, int C) {
   return k_se_dgate(ST(s), t, z, sc, sh, dgate, N, HW, C);

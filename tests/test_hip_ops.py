@@ -1137,6 +1137,124 @@ def test_dwconv_fwd_bwd(N, H, W, Cc, stride):
     assert_close(dw.view(Cc, 1, 3, 3), w.grad, TOL, "dwconv bwd weight")
 
 
+@pytest.mark.parametrize("N,H,W,Cc,stride,slots", [(3, 14, 14, 64, 1, 16), (2, 9, 11, 96, 2, 4), (2, 40, 36, 32, 1, 1)])
+def test_elementwise_consumers_with_folded_batchnorm(N, H, W, Cc, stride, slots):
+    """mmvqa_*_fold (EfficientNetV2 path, round 3): the depthwise convolution (forward: BatchNorm of its input; data /
+    weight gradient: backward coefficients of its output's BatchNorm), the squeeze-excite pooling and the block end derive
+    the coefficients from raw sums inside the launch.  Same results as the plain entries on coefficients computed in
+    float64 here; published coefficients, running statistics (k-fold rule, reps = 2), batch counter, dgamma / dbeta
+    against the formulas of mmvqa_bn_coef_fwd / _bwd; tile and pixel-strided kernels (40x36 does not fit in LDS)."""
+    torch.manual_seed(33)
+    z1 = torch.randn(N, Cc, H, W) * 1.5 + 0.3
+    gamma, beta = torch.rand(Cc) + 0.5, torch.randn(Cc) * 0.3
+    M = N * H * W
+    sums = torch.stack([z1.double().sum(dim=(0, 2, 3)), (z1.double() ** 2).sum(dim=(0, 2, 3))], 1)
+    mean = sums[:, 0] / M
+    var = sums[:, 1] / M - mean * mean
+    sc = (gamma.double() / torch.sqrt(var + 1e-5)).float()
+    sh = (beta.double() - mean * sc.double()).float()
+    w = torch.randn(Cc, 9) / 3
+    pt, _ = _same_pad(H, 3, stride)
+    OH, OW = -(-H // stride), -(-W // stride)
+    z1d, wd, scd, shd, gd, bd = nhwc(z1), w.to(dev()), sc.to(dev()), sh.to(dev()), gamma.to(dev()), beta.to(dev())
+
+    def fwd_fold(publish=1):
+        outs = [torch.zeros(Cc, device=dev()) for _ in range(4)]
+        rm, rv = torch.full((Cc,), 0.25, device=dev()), torch.full((Cc,), 2.0, device=dev())
+        nbt = torch.zeros(1, dtype=torch.int64, device=dev())
+        st = _spread(sums, slots)
+        f = _fold(st, slots, 0, publish, M, gd, beta=bd, out0=outs[0], out1=outs[1], out2=outs[2], out3=outs[3], run_mean=rm,
+                  run_var=rv, nbt=nbt, reps=2)
+        return f, (st, outs, rm, rv, nbt)
+
+    def check_published(keep, what):
+        st, outs, rm, rv, nbt = keep
+        assert_close(outs[0], sc, 1e-6, what + ": scale")
+        assert_close(outs[1], sh, 1e-5, what + ": shift")
+        assert_close(outs[3], (1.0 / torch.sqrt(var + 1e-5)).float(), 1e-6, what + ": invstd")
+        unb = var * M / (M - 1)
+        assert_close(rm, (0.81 * 0.25 + 0.19 * mean).float(), 1e-5, what + ": running mean (2 updates)")
+        assert_close(rv, (0.81 * 2.0 + 0.19 * unb).float(), 1e-5, what + ": running var (2 updates)")
+        assert int(nbt) == 2, what
+
+    # depthwise forward
+    lib = L.lib()
+    outp, outf = torch.zeros(N * OH * OW, Cc, device=dev()), torch.zeros(N * OH * OW, Cc, device=dev())
+    stp, stf = (torch.zeros(L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=dev()) for _ in range(2))
+    L.check(lib.mmvqa_dwconv_fwd(L.stream_ptr(), P(z1d), P(scd), P(shd), P(wd), P(outp), P(stp), N, H, W, Cc, OH, OW, stride, pt))
+    f, keep = fwd_fold()
+    L.check(lib.mmvqa_dwconv_fwd_fold(L.stream_ptr(), P(z1d), None, None, P(wd), P(outf), P(stf), N, H, W, Cc, OH, OW, stride, pt,
+                                      C.byref(f)))
+    torch.cuda.synchronize()
+    assert_close(outf, outp, 2e-6, "dwconv forward: fold vs coefficient arrays")
+    assert_close(stf.sum(0), stp.sum(0), 1e-6, "dwconv forward statistics")
+    check_published(keep, "dwconv forward")
+    # squeeze-excite pooling (a fold that does not publish leaves the outputs alone)
+    poolp, poolf = torch.zeros(N, Cc, device=dev()), torch.zeros(N, Cc, device=dev())
+    L.check(lib.mmvqa_se_pool(L.stream_ptr(), P(z1d), P(scd), P(shd), P(poolp), N, H * W, Cc))
+    f, keep = fwd_fold(publish=0)
+    L.check(lib.mmvqa_se_pool_fold(L.stream_ptr(), P(z1d), None, None, P(poolf), N, H * W, Cc, C.byref(f)))
+    torch.cuda.synchronize()
+    assert_close(poolf, poolp, 2e-6, "se_pool: fold vs coefficient arrays")
+    assert float(keep[1][0].abs().max()) == 0.0 and int(keep[4]) == 0, "a non-publishing fold wrote something"
+    f, keep = fwd_fold()
+    L.check(lib.mmvqa_se_pool_fold(L.stream_ptr(), P(z1d), None, None, P(poolf), N, H * W, Cc, C.byref(f)))
+    torch.cuda.synchronize()
+    check_published(keep, "se_pool")
+    # block end: silu(bn(z)) + idn, and bn(z) alone
+    idn = torch.randn(M, Cc, device=dev())
+    for pre, with_idn in ((L.ACT_SILU, True), (L.ACT_NONE, True), (L.ACT_NONE, False)):
+        op, of = torch.zeros(M, Cc, device=dev()), torch.zeros(M, Cc, device=dev())
+        L.check(lib.mmvqa_bn_act_add(L.stream_ptr(), P(z1d), P(scd), P(shd), pre, P(idn) if with_idn else None, None, None, 0,
+                                     L.ACT_NONE, P(op), M, Cc))
+        f, keep = fwd_fold()
+        L.check(lib.mmvqa_bn_act_add_fold(L.stream_ptr(), P(z1d), C.byref(f), pre, P(idn) if with_idn else None, None, L.ACT_NONE,
+                                          P(of), M, Cc))
+        torch.cuda.synchronize()
+        assert_close(of, op, 2e-6, f"block end (pre {pre}, idn {with_idn}): fold vs coefficient arrays")
+        check_published(keep, "block end")
+    # backward coefficients of the depthwise output's BatchNorm: dz2 = P*g2 + Q*z2 + R from (sum g, sum g*xhat)
+    Mo = N * OH * OW
+    g2 = torch.randn(Mo, Cc, device=dev())
+    mu2, is2, gam2 = torch.randn(Cc) * 0.2, torch.rand(Cc) + 0.5, torch.rand(Cc) + 0.5
+    bsum = torch.stack([torch.randn(Cc).double() * 5, torch.randn(Cc).double() * 5], 1)
+    p = gam2.double() * is2.double()
+    c1, c2 = bsum[:, 0] / Mo, bsum[:, 1] / Mo
+    Pc, Qc, Rc = p.float(), (-p * c2 * is2.double()).float(), (p * (c2 * is2.double() * mu2.double() - c1)).float()
+    coef = [t.to(dev()) for t in (Pc, Qc, Rc, mu2, is2, gam2)]
+    mu1, is1 = (t.to(dev()) for t in (mean.float(), (1.0 / torch.sqrt(var + 1e-5)).float()))
+    res = {}
+    for name in ("plain", "fold"):
+        g1 = torch.zeros(M, Cc, device=dev())
+        bst = torch.zeros(L.STAT_SLOTS, Cc, 2, dtype=torch.float64, device=dev())
+        dw = torch.zeros(Cc, 9, device=dev())
+        if name == "plain":
+            L.check(lib.mmvqa_dwconv_bwd_data(L.stream_ptr(), P(g2), P(outp), P(coef[0]), P(coef[1]), P(coef[2]), P(wd), P(z1d), P(scd),
+                                              P(shd), P(mu1), P(is1), P(g1), P(bst), N, H, W, Cc, OH, OW, stride, pt))
+            L.check(lib.mmvqa_dwconv_bwd_weight(L.stream_ptr(), P(g2), P(outp), P(coef[0]), P(coef[1]), P(coef[2]), P(z1d), P(scd), P(shd),
+                                                P(dw), N, H, W, Cc, OH, OW, stride, pt))
+        else:
+            st = _spread(bsum, slots)
+            pub = [torch.zeros(Cc, device=dev()) for _ in range(3)]
+            dg, db = torch.full((Cc,), 1.5, device=dev()), torch.full((Cc,), -0.5, device=dev())
+            fd = _fold(st, slots, 1, 1, Mo, coef[5], mean=coef[3], invstd=coef[4], out0=pub[0], out1=pub[1], out2=pub[2], dgamma=dg, dbeta=db)
+            fw = _fold(st, slots, 1, 0, Mo, coef[5], mean=coef[3], invstd=coef[4])
+            L.check(lib.mmvqa_dwconv_bwd_data_fold(L.stream_ptr(), P(g2), P(outp), None, None, None, P(wd), P(z1d), P(scd), P(shd),
+                                                   P(mu1), P(is1), P(g1), P(bst), N, H, W, Cc, OH, OW, stride, pt, C.byref(fd)))
+            L.check(lib.mmvqa_dwconv_bwd_weight_fold(L.stream_ptr(), P(g2), P(outp), None, None, None, P(z1d), P(scd), P(shd), P(dw),
+                                                     N, H, W, Cc, OH, OW, stride, pt, C.byref(fw)))
+            torch.cuda.synchronize()
+            for got, want, nm in zip(pub, (Pc, Qc, Rc), "PQR"):
+                assert_close(got, want, 1e-5, "published " + nm)
+            assert_close(dg, 1.5 + bsum[:, 1].float(), 1e-5, "dgamma += sum g*xhat")
+            assert_close(db, -0.5 + bsum[:, 0].float(), 1e-5, "dbeta += sum g")
+        torch.cuda.synchronize()
+        res[name] = (g1, bst.sum(0), dw)
+    assert_close(res["fold"][0], res["plain"][0], 1e-5, "dwconv data gradient: fold vs coefficient arrays")
+    assert_close(res["fold"][1], res["plain"][1], 1e-5, "dwconv data gradient statistics")
+    assert_close(res["fold"][2], res["plain"][2], 1e-5, "dwconv weight gradient: fold vs coefficient arrays")
+
+
 def test_squeeze_excite_and_block_end_kernels():
     """se_pool / se_dgate / act_bwd_stats / bn_act_add vs plain torch (C not a multiple of 64, HW not a multiple of 16)"""
     torch.manual_seed(21)
