@@ -896,6 +896,7 @@ __global__ void supcon_reduce_kernel(const float* __restrict__ row_loss, float* 
 }
 
 // =========================================================================== Adam (torch defaults; roco_train.py:90)
+template <int U>
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n4, float step_size, float b1, float omb1, float b2,
                             float omb2, float eps, float bc2_sqrt, float gscale, int zero_grad) {
@@ -919,17 +920,23 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
   f32x4* M4 = reinterpret_cast<f32x4*>(m); f32x4* V4 = reinterpret_cast<f32x4*>(v);
   const f32x4 zero = {0, 0, 0, 0};
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + stride < n4; i += 2 * stride) {
-    const long j = i + stride;
-    f32x4 p0 = P4[i], g0 = G4[i], m0 = __builtin_nontemporal_load(M4 + i), v0 = __builtin_nontemporal_load(V4 + i);
-    f32x4 p1 = P4[j], g1 = G4[j], m1 = __builtin_nontemporal_load(M4 + j), v1 = __builtin_nontemporal_load(V4 + j);
-    upd(p0, g0, m0, v0);
-    upd(p1, g1, m1, v1);
-    P4[i] = p0; __builtin_nontemporal_store(m0, M4 + i); __builtin_nontemporal_store(v0, V4 + i);
-    P4[j] = p1; __builtin_nontemporal_store(m1, M4 + j); __builtin_nontemporal_store(v1, V4 + j);
-    if (zero_grad) { G4[i] = zero; G4[j] = zero; }
+  for (; i + (U - 1) * stride < n4; i += U * stride) {
+    f32x4 pv[U], gv[U], mv[U], vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long j = i + u * stride;
+      pv[u] = P4[j]; gv[u] = G4[j]; mv[u] = __builtin_nontemporal_load(M4 + j); vv[u] = __builtin_nontemporal_load(V4 + j);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) upd(pv[u], gv[u], mv[u], vv[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long j = i + u * stride;
+      P4[j] = pv[u]; __builtin_nontemporal_store(mv[u], M4 + j); __builtin_nontemporal_store(vv[u], V4 + j);
+      if (zero_grad) G4[j] = zero;
+    }
   }
-  if (i < n4) {
+  for (; i < n4; i += stride) {
     f32x4 p0 = P4[i], g0 = G4[i], m0 = M4[i], v0 = V4[i];
     upd(p0, g0, m0, v0);
     P4[i] = p0; M4[i] = m0; V4[i] = v0;
@@ -1260,10 +1267,15 @@ int k_adam(hipStream_t st, float* p, float* g, float* m, float* v, long n, doubl
   // MMVQA_ADAM_WGS: cap on the workgroups of one launch (A/B: a ranged launch beside the backward pass takes wave slots
   // and bandwidth from the GEMMs it shares the chip with)
   const char* cap_s = getenv("MMVQA_ADAM_WGS");
-  const int cap = cap_s ? atoi(cap_s) : 4096;
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, cap > 0 ? cap : 4096)), dim3(256), 0, st, p, g, m, v, n / 4,
-                     (float)(lr / bc1), (float)b1, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps,
-                     (float)sqrt(bc2), gscale, zero_grad);
+  const int cap = cap_s ? atoi(cap_s) : 16384;   // (tools/adam_bench.py: 0.80 ms at 4096, 0.705 ms = 6.0 TB/s at 16384, 133 M parameters)
+  // MMVQA_ADAM_UNROLL: float4 of each array in flight per thread (A/B; default 2: one per iteration left the pass at 2.4 TB/s)
+  static const int unroll = getenv("MMVQA_ADAM_UNROLL") ? atoi(getenv("MMVQA_ADAM_UNROLL")) : 2;
+#define ADAM_GO(U_)                                                                                                       \
+  hipLaunchKernelGGL(adam_kernel<U_>, dim3(grid_for(n / 4, 256, cap > 0 ? cap : 16384)), dim3(256), 0, st, p, g, m, v, n / 4, \
+                     (float)(lr / bc1), (float)b1, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps,            \
+                     (float)sqrt(bc2), gscale, zero_grad)
+  if (unroll >= 4) ADAM_GO(4); else if (unroll == 3) ADAM_GO(3); else if (unroll == 1) ADAM_GO(1); else ADAM_GO(2);
+#undef ADAM_GO
   KERNEL_CHECK_RET();
   return MMVQA_OK;
 }
