@@ -279,6 +279,7 @@ def main():
         if CONFIG == 5:    # VQA head + ASLSingleLabel
             loss, _ = TR.vqa_step(model, opt, red, world, (img, ids, seg, mask, tgt), mmvqa_amd.asl_loss)
             return [loss.detach()]
+        mark("step_a")
         logits = model(img, ids, seg, mask)
         mark("loss_fwd_a")
         loss, _, stats = mmvqa_amd.mlm_loss(logits, tgt)
@@ -321,6 +322,17 @@ def main():
     # run beside the data-gradient chain, so a launch's duration includes the time it shares the chip: the average
     # agrees with the steady-state rocprofv3 kernel trace (profiles/round2_kernel_stats_steady_cfg2.csv).
     roof = None
+    phases = None
+    if not a.no_roofline and CONFIG in (2, 3):
+        # where the step's wall time goes: one more step as the timed ones run (no per-launch events), torch events on the
+        # caller's stream between the phases (every phase ends with that stream joined to the side stream)
+        step(timed_parts=True)
+        torch.cuda.synchronize()
+        ph = lambda a_, b_: marks[a_].elapsed_time(marks[b_])
+        phases = dict(forward_ms=ph("step_a", "loss_fwd_a"), loss_ms=ph("loss_fwd_a", "loss_fwd_b"),
+                      backward_ms=ph("loss_fwd_b", "adam_a"), adam_ms=ph("adam_a", "adam_b"),
+                      note="forward = CNN + taps + encoder + heads; loss = log-softmax / NLL / accuracy pass; backward incl. its "
+                           "dlogits pass and the join with the weight-gradient stream")
     if not a.no_roofline:
         model.profile(True)
         step(timed_parts=True)
@@ -356,6 +368,8 @@ def main():
                     # matrix work outside igemm_kernel (register-resident stem tap, squeeze-excite layers: configs 3-5)
                     matrix_outside_igemm=dict(launches=pr["matrix_other"]["launches"], ms=pr["matrix_other"]["ms"],
                                               gflop=pr["matrix_other"]["flops"] / 1e9))
+        if phases is not None:
+            roof["phases"] = phases
         if CONFIG in (2, 3):
             roof["blocks"] = per_block(regs, marks, model, a)
         # the HBM-bound kernels one by one: algorithmic bytes (every tensor read / written once, fp32) over the HIP-event

@@ -250,6 +250,7 @@ void mmvqa_engine_destroy(mmvqa_engine* e) {
   if (!e) return;
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->side) (void)hipStreamDestroy(e->side);
+  if (e->side2) (void)hipStreamDestroy(e->side2);
   delete e;
 }
 int mmvqa_engine_num_tensors(const mmvqa_engine* e) { return e ? (int)e->specs.size() : 0; }

@@ -391,8 +391,8 @@ size_t engine_plan(mmvqa_engine* e, int B, int T, int IH, int IW) {
   }
   }
   e->vis = a.f((size_t)5 * B * H);
-  for (int i = 0; i < 2; ++i) e->sk_ws[i] = a.f(SK_WS_FLOATS);   // split-K partial tiles (main / side stream)
-  for (int i = 0; i < 2; ++i) e->sk_cnt[i] = a.f(SK_CNT_N);      // arrival tickets of persistent launches
+  for (int i = 0; i < 3; ++i) e->sk_ws[i] = a.f(SK_WS_FLOATS);   // split-K partial tiles (caller's / side / tap stream)
+  for (int i = 0; i < 3; ++i) e->sk_cnt[i] = a.f(SK_CNT_N);      // arrival tickets of ticketed / persistent launches
   e->dvis = a.f((size_t)5 * B * H);
   e->du = a.f(max_tapM * H);
   for (int i = 0; i < 3; ++i) e->gbuf[i] = a.f(max_io);
@@ -507,7 +507,7 @@ static GemmParams gp_linear_geom() {
 static void set_sk(mmvqa_engine* e, hipStream_t st, GemmParams& g) {
   static const bool off = getenv("MMVQA_NO_SK_WS") != nullptr;   // A/B switch: no K split of forward / data-gradient products
   if (off) return;
-  const int which = (e->side && st == e->side) ? 1 : 0;
+  const int which = (e->side && st == e->side) ? 1 : ((e->side2 && st == e->side2) ? 2 : 0);
   g.sk_ws = WS(e->sk_ws[which]);
   g.sk_ws_floats = (long long)SK_WS_FLOATS;
   g.sk_cnt = reinterpret_cast<unsigned int*>(WS(e->sk_cnt[which]));
@@ -815,6 +815,36 @@ struct SideCtx {
     }
     sd = on ? e->side : st;
   }
+  // third stream for the tap backward: four long launch groups (2.4 ms per config-2 step) that are needed only when the
+  // chain reaches their layer; queued on `sd` they sat in front of the first weight gradients, whose completion the chain
+  // waits for before it reuses a gradient buffer.  MMVQA_TAP_STREAM_OFF=1 puts them back on `sd` (A/B switch).
+  hipStream_t tap_stream() {
+    static const bool off = getenv("MMVQA_TAP_STREAM_OFF") != nullptr;
+    if (!on || off) return sd;
+    if (!e->side2) {
+      int least = 0, greatest = 0;
+      bool ok;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+        ok = hipStreamCreateWithPriority(&e->side2, hipStreamNonBlocking, least) == hipSuccess;
+      else
+        ok = hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking) == hipSuccess;
+      if (!ok) { e->side2 = nullptr; return sd; }
+    }
+    return e->side2;
+  }
+  void fork_to(hipStream_t s) {   // s starts behind everything queued on the caller's stream so far
+    if (!on || s == st) return;
+    hipEvent_t ev = next_event();
+    if (!ev) return;
+    (void)hipEventRecord(ev, st);
+    (void)hipStreamWaitEvent(s, ev, 0);
+  }
+  hipEvent_t mark_on(hipStream_t s) {
+    if (!on) return nullptr;
+    hipEvent_t ev = next_event();
+    if (ev) (void)hipEventRecord(ev, s);
+    return ev;
+  }
   hipEvent_t next_event() {
     if (e->ev_next == e->ev_pool.size()) {
       hipEvent_t ev;
@@ -933,14 +963,15 @@ static int resnet_backward(mmvqa_engine* e, hipStream_t st) {
   // taps on layer1..3 and the stem produce side gradients T_k that are only needed when the chain reaches
   // their layer: side stream (they share the `du` scratch with the tap above, hence the fork after it)
   hipEvent_t ev_tap[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  sc.fork();
+  hipStream_t ts = sc.tap_stream();
+  sc.fork_to(ts);
   for (int k = 1; k <= 3; ++k) {
     const BlockRef& blk = e->blocks[e->layer_end[3 - k]];
-    TRY(tap_bwd(e, sd, k, WS(blk.out), nullptr, WS(e->tapgrad[k]), EpiOpt()));
-    ev_tap[k] = sc.mark();
+    TRY(tap_bwd(e, ts, k, WS(blk.out), nullptr, WS(e->tapgrad[k]), EpiOpt()));
+    ev_tap[k] = sc.mark_on(ts);
   }
-  TRY(tap_bwd(e, sd, 4, WS(e->z0), &e->stem_bn, WS(e->tapgrad[4]), EpiOpt()));
-  ev_tap[4] = sc.mark();
+  TRY(tap_bwd(e, ts, 4, WS(e->z0), &e->stem_bn, WS(e->tapgrad[4]), EpiOpt()));
+  ev_tap[4] = sc.mark_on(ts);
   hipEvent_t ev_g1 = nullptr, ev_g2 = nullptr, ev_prevG = nullptr;   // side readers of g1buf / g2buf / previous G
   long long hi_mark = e->enc_lo;    // gradients in [hi_mark, end) were announced by the caller; fc + taps sit below
   for (int i = nb - 1; i >= 0; --i) {
@@ -1196,6 +1227,7 @@ static int effnet_backward(mmvqa_engine* e, hipStream_t st) {
       TRY(tap_bwd(e, sd, b.feature, WS(b.out), nullptr, WS(e->tapgrad[b.feature]), EpiOpt()));
       ev_tap[b.feature] = scx.mark();
     }
+  // (a stream of their own for these taps, as the ResNet path has, measured neutral here: 22.74 / 22.76 / 22.84 vs 22.67 / 22.75 / 22.72 ms)
   for (int i = nb - 1; i >= 0; --i) {
     EffBlock& b = e->eff[i];
     const float* G = WS(e->gbuf[cur]);
@@ -1574,7 +1606,7 @@ static int prepare_workspace(mmvqa_engine* e, hipStream_t st) {
     const mmvqa_engine::PixGeom& q = kv.second;
     TRY(k_pixmask(st, reinterpret_cast<int*>(WS(q.off)), q.N, q.OH, q.OW, q.H, q.W, q.KH, q.KH, q.stride, q.pad));
   }
-  for (int i = 0; i < 2; ++i) HIP_CHECK_RET(hipMemsetAsync(WS(e->sk_cnt[i]), 0, SK_CNT_N * sizeof(unsigned int), st));
+  for (int i = 0; i < 3; ++i) HIP_CHECK_RET(hipMemsetAsync(WS(e->sk_cnt[i]), 0, SK_CNT_N * sizeof(unsigned int), st));
   e->ws_ready = true;
   return MMVQA_OK;
 }

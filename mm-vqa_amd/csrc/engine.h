@@ -110,7 +110,7 @@ struct mmvqa_engine {
   std::vector<BlockRef> blocks;
   std::vector<EffBlock> eff;     // EfficientNetV2 body (cnn == 1)
   size_t eff_a0 = 0;             // materialised stem activation silu(bn1(conv_stem))
-  size_t sk_ws[2] = {0, 0};      // split-K partial-tile scratch per stream (igemm sk_ws)
+  size_t sk_ws[3] = {0, 0, 0};   // split-K partial-tile scratch per stream (igemm sk_ws): caller's, side, tap stream
   size_t eff_gA[2] = {0, 0}, eff_gB[2] = {0, 0}, eff_separt = 0, eff_se[6];   // backward scratch ([pixels, mid], two of each: blocks alternate,
                                                                             // the side stream still reads block i's while block i-1 writes), squeeze-excite temporaries
   int layer_end[4];          // index of last block of layer1..4
@@ -150,6 +150,8 @@ struct mmvqa_engine {
   IgemmTuner tuner;
   // ---- second stream: weight-gradient GEMMs and tap backward run beside the data-gradient chain
   hipStream_t side = nullptr;
+  hipStream_t side2 = nullptr;   // the tap backward (needed late, long launches): a stream of its own so that it does not sit in
+                                 // front of the weight gradients the dependency chain waits for
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
   int use_side = 1;
@@ -160,7 +162,7 @@ struct mmvqa_engine {
   struct PixGeom { int N, OH, OW, H, W, KH, stride, pad; size_t off; };
   std::map<std::string, PixGeom> pixmask_off;
   bool ws_ready = false;                        // persistent workspace state (tables, tickets) is in place
-  size_t sk_cnt[2] = {0, 0};                    // arrival tickets of persistent launches (main / side stream)
+  size_t sk_cnt[3] = {0, 0, 0};                 // arrival tickets of ticketed / persistent launches (one set per stream)
   // ---- gradient-ready notifications (data-parallel overlap): called on the host right after the kernels that
   // complete grads[lo, hi) have been enqueued and the main stream has been ordered behind them
   void (*grad_cb)(void* user, long long lo, long long hi) = nullptr;
