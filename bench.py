@@ -370,6 +370,10 @@ def main():
                                               gflop=pr["matrix_other"]["flops"] / 1e9))
         if phases is not None:
             roof["phases"] = phases
+            wall = phases["forward_ms"] + phases["backward_ms"]
+            roof["step_level"] = dict(achieved=g["flops"] / (wall * 1e-3) / 1e12, frac=g["flops"] / (wall * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                      note="GEMM FLOPs of the step over the WALL time of forward + backward (every other kernel, gap and "
+                                           "stream join included): unlike `frac` it does not shrink when launches overlap")
         if CONFIG in (2, 3):
             roof["blocks"] = per_block(regs, marks, model, a)
         # the HBM-bound kernels one by one: algorithmic bytes (every tensor read / written once, fp32) over the HIP-event
