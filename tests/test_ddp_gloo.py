@@ -36,6 +36,25 @@ def _worker(rank, world, port, q):
         red2.start(hi=6000)
         red2.finish()
         ok2 = torch.allclose(g2, mine + other, atol=1e-6)
+        # 2b. the per-bucket callback an overlapped optimizer hangs on (optim.FusedAdam.overlap_backward): called once per
+        # exchanged range with that range's work handle; the ranges partition the buffer; after work.wait() the range is reduced
+        g3 = mine.clone()
+        red3 = GradReducer(g3, bucket_mb=0.01)
+        seen = []
+
+        def after(lo, hi, work=None, stream=None):
+            work.wait()
+            seen.append((lo, hi, bool(torch.allclose(g3[lo:hi], (mine + other)[lo:hi], atol=1e-6))))
+        red3.after_bucket = after
+        assert red3.exchanges()
+        red3.start(lo=6000)
+        red3.start(hi=6000)
+        red3.finish()
+        pos = 0
+        for lo, hi, good in sorted(seen):
+            ok2 = ok2 and lo == pos and good
+            pos = hi
+        ok2 = ok2 and pos == 10007 and len(seen) >= len(red3.buckets)
         # 3. SupCon over the global view set: loss identical on both ranks, gradient = slice of the global one
         torch.manual_seed(7)
         full = torch.nn.functional.normalize(torch.randn(2 * world, 2, 16), dim=2)   # [N_global, 2 views, D]
