@@ -25,7 +25,7 @@ def build():
     os.makedirs(out, exist_ok=True)
     exp = os.environ.get("IGEMM_EXP", "")
     lib = os.path.join(out, "libmmvqa_trace%s.so" % exp.replace("-D", "_").replace(" ", ""))
-    srcs = [os.path.join(src, f) for f in ("igemm.hip", "attention.hip", "elementwise.hip", "augment.hip", "se.hip", "tapthin.hip", "engine.cpp",
+    srcs = [os.path.join(src, f) for f in ("igemm.hip", "attention.hip", "elementwise.hip", "augment.hip", "se.hip", "tapthin.hip", "qkvattn.hip", "engine.cpp",
                                            "abi.cpp")]
     if os.path.exists(lib) and all(os.path.getmtime(lib) > os.path.getmtime(s) for s in srcs):
         return lib
