@@ -902,8 +902,20 @@ static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
   // The five taps (1x1 conv -> act -> global average pool) and the downsample convolutions do not feed the
   // bottleneck chain: they run on the side stream beside it (most of the chain's launches fill 196 of 256 CUs).
   SideCtx sc(e, st);
-  sc.fork();
-  TRY(tap_fwd(e, sc.sd, 4, WS(e->z0), &e->stem_bn));
+  // A tap is queued on the side stream BEHIND the next block's downsample convolution (MMVQA_TAP_FIRST=1: in front of it, as
+  // before round 3's last change): the block end of that block waits for the downsample branch, and a 0.1-0.6 ms tap in
+  // front of it stalled the chain at every layer start (the stem tap alone is 634 us against 220 us of layer1.0's
+  // three convolutions).
+  static const bool tap_first = getenv("MMVQA_TAP_FIRST") != nullptr;
+  int pend_tap = -1;
+  const float* pend_x = nullptr;
+  const BNRef* pend_bn = nullptr;
+  if (tap_first) {
+    sc.fork();
+    TRY(tap_fwd(e, sc.sd, 4, WS(e->z0), &e->stem_bn));
+  } else {
+    pend_tap = 4; pend_x = WS(e->z0); pend_bn = &e->stem_bn;
+  }
   RUNB(HB_MAXPOOL_FWD, 4.0 * B * e->SH * e->SW * w + 5.0 * B * e->PH * e->PW * w, k_maxpool_fwd(st, WS(e->z0), WS(e->stem_bn.scale), WS(e->stem_bn.shift), WS(e->p0),
                                    reinterpret_cast<unsigned char*>(WS(e->pool_idx)), B, e->SH, e->SW, w, e->PH,
                                    e->PW));
@@ -916,6 +928,11 @@ static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
       sc.fork();
       TRY(conv_fwd(e, sc.sd, b.cd, x, nullptr, B, b.H, b.W, b.OH, b.OW, WS(b.zd), b.bd));
       ev_ds = sc.mark();
+    }
+    if (pend_tap >= 0) {   // the tap on the previous layer's output (or the stem's), behind this block's downsample branch
+      if (!b.has_ds) sc.fork();
+      TRY(tap_fwd(e, sc.sd, pend_tap, pend_x, pend_bn));
+      pend_tap = -1;
     }
     TRY(conv_fwd(e, st, b.c1, x, nullptr, B, b.H, b.W, b.H, b.W, WS(b.z1), b.b1));
     TRY(conv_fwd(e, st, b.c2, WS(b.z1), &b.b1, B, b.H, b.W, b.OH, b.OW, WS(b.z2), b.b2));
@@ -937,10 +954,18 @@ static int resnet_forward(mmvqa_engine* e, hipStream_t st) {
     }
     x = WS(b.out);
     if ((int)i == e->layer_end[layer]) {
-      sc.fork();
-      TRY(tap_fwd(e, sc.sd, 3 - layer, x, nullptr));
+      if (tap_first) {
+        sc.fork();
+        TRY(tap_fwd(e, sc.sd, 3 - layer, x, nullptr));
+      } else {
+        pend_tap = 3 - layer; pend_x = x; pend_bn = nullptr;
+      }
       ++layer;
     }
+  }
+  if (pend_tap >= 0) {   // the tap on the last layer's output
+    sc.fork();
+    TRY(tap_fwd(e, sc.sd, pend_tap, pend_x, pend_bn));
   }
   sc.need(sc.mark());   // join: the embedding reads the visual tokens
   return MMVQA_OK;
