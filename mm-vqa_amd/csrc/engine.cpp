@@ -873,6 +873,38 @@ struct SideCtx {
   }
 };
 
+// Weight gradients of the linear layers (heads, encoder) on the side stream: the 512-row products of the encoder fill
+// 96-384 of 256 CUs x 2 slots, so a weight gradient beside the data gradient it shares its input with is nearly free.
+// SideReads remembers, per scratch buffer, the event of the last side launch that READS it; the chain calls write(ptr)
+// before it overwrites that buffer.  MMVQA_ENC_SIDE_OFF=1: everything on the caller's stream (A/B switch).
+struct SideReads {
+  SideCtx& sc;
+  bool on;
+  std::vector<std::pair<const void*, hipEvent_t>> rd;
+  explicit SideReads(SideCtx& s) : sc(s) {
+    static const bool off = getenv("MMVQA_ENC_SIDE_OFF") != nullptr;
+    on = sc.on && !off;
+  }
+  void read(const void* p) {
+    hipEvent_t ev = sc.mark();
+    for (auto& kv : rd) if (kv.first == p) { kv.second = ev; return; }
+    rd.emplace_back(p, ev);
+  }
+  void write(const void* p) {
+    for (auto& kv : rd) if (kv.first == p && kv.second) { sc.need(kv.second); kv.second = nullptr; }
+  }
+  void join() { if (on) sc.need(sc.mark()); }
+};
+// dW += dy^T x (+ bias gradient) beside the chain: starts behind everything queued on the caller's stream so far
+static int lin_wgrad_side(mmvqa_engine* e, SideReads& sr, hipStream_t st, const float* dy, int dy_ld, const float* x, int x_ld, long M,
+                          const LinRef& L, bool bias_from_colsum) {
+  if (!sr.on) return lin_wgrad(e, st, dy, dy_ld, x, x_ld, M, L, bias_from_colsum);
+  sr.sc.fork();
+  TRY(lin_wgrad(e, sr.sc.sd, dy, dy_ld, x, x_ld, M, L, bias_from_colsum));
+  sr.read(dy);
+  return MMVQA_OK;
+}
+
 static void notify(mmvqa_engine* e, SideCtx& sc, long long lo, long long hi) {
   if (!e->grad_cb || hi <= lo) return;
   sc.need(sc.mark());   // weight gradients of the range may still be queued on the side stream
@@ -1415,7 +1447,7 @@ static int bert_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, cons
 }
 
 // dz (in t_a) -> dx (left in t_a)
-static int bert_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
+static int bert_backward(mmvqa_engine* e, hipStream_t st, const float* x_in, SideReads& sr) {
   REG(REG_ENC);
   const mmvqa_model_desc& d = e->d;
   const int H = d.hidden;
@@ -1428,23 +1460,29 @@ static int bert_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
     // FFN branch: z = y + drop(fc2(gelu(fc1(norm1(y)))))
     const float* dzd = dz;
     if (p > 0.f) {
+      sr.write(WS(e->t_b));
       RUNB(HB_DROPOUT_COPY, 8.0 * M * H, k_dropout_copy(st, dz, WS(e->t_b), M * H, p, site_seed(e, i, 2)));
       dzd = WS(e->t_b);
     }
-    TRY(lin_wgrad(e, st, dzd, H, WS(L.h1), 4 * H, M, L.fc2, true));
+    TRY(lin_wgrad_side(e, sr, st, dzd, H, WS(L.h1), 4 * H, M, L.fc2, true));
+    sr.write(WS(e->t_big));
     TRY(lin_dgrad(e, st, dzd, H, M, L.fc2, WS(e->t_big), 4 * H, ACT_GELU, WS(L.pre1), 4 * H, GRD(L.fc1.b), nullptr, 0));
-    TRY(lin_wgrad(e, st, WS(e->t_big), 4 * H, WS(L.xn2), H, M, L.fc1, false));
+    TRY(lin_wgrad_side(e, sr, st, WS(e->t_big), 4 * H, WS(L.xn2), H, M, L.fc1, false));
+    sr.write(WS(e->t_c));
     TRY(lin_dgrad(e, st, WS(e->t_big), 4 * H, M, L.fc1, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0));
     // dy = LN'(dxn2) + dz
+    sr.write(WS(e->t_d));
     TRY(ln_bwd(e, st, WS(e->t_c), WS(L.y), e->norm1, WS(L.mean2), WS(L.rstd2), dz, WS(e->t_d), M));
     float* dy = WS(e->t_d);
     // attention branch: y = x + drop(proj(attn(norm1(x))))
     const float* dyd = dy;
     if (p > 0.f) {
+      sr.write(WS(e->t_b));
       RUNB(HB_DROPOUT_COPY, 8.0 * M * H, k_dropout_copy(st, dy, WS(e->t_b), M * H, p, site_seed(e, i, 1)));
       dyd = WS(e->t_b);
     }
-    TRY(lin_wgrad(e, st, dyd, H, WS(L.ctx), H, M, L.proj, true));
+    TRY(lin_wgrad_side(e, sr, st, dyd, H, WS(L.ctx), H, M, L.proj, true));
+    sr.write(WS(e->t_c));
     TRY(lin_dgrad(e, st, dyd, H, M, L.proj, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0));  // dctx
     AttnParams a;
     memset(&a, 0, sizeof(a));
@@ -1457,10 +1495,13 @@ static int bert_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
     a.dout = WS(e->t_c);
     float* dqkv = WS(e->t_big);
     a.dq = dqkv; a.dk = dqkv + H; a.dv = dqkv + 2 * H;
+    sr.write(dqkv);
     TRY(attn_call(e, st, a, H / d.heads, 1));
     { REG(REG_QKV);
-      TRY(lin_wgrad(e, st, dqkv, 3 * H, WS(L.xn1), H, M, L.qkv, true));
+      TRY(lin_wgrad_side(e, sr, st, dqkv, 3 * H, WS(L.xn1), H, M, L.qkv, true));
+      sr.write(WS(e->t_c));
       TRY(lin_dgrad(e, st, dqkv, 3 * H, M, L.qkv, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0)); }  // dxn1
+    sr.write(dz);
     TRY(ln_bwd(e, st, WS(e->t_c), x, e->norm1, WS(L.mean1), WS(L.rstd1), dy, dz, M));
   }
   return MMVQA_OK;
@@ -1583,14 +1624,17 @@ static int heads_forward(mmvqa_engine* e, hipStream_t st, const float* h) {
 
 // produces dh (gradient wrt the encoder output) in t_a
 static int heads_backward(mmvqa_engine* e, hipStream_t st, const float* h, const float* dlogits, int dl_ld,
-                          const float* dfeat) {
+                          const float* dfeat, SideReads& sr) {
   REG(REG_HEAD);
   const mmvqa_model_desc& d = e->d;
   const int H = d.hidden;
   const long M = (long)e->B * e->T;
   const long HM = d.head_kind == 1 ? e->B : M;
   const float* hin = d.head_kind == 1 ? WS(e->hd_pool) : h;
-  {  // classifier[2]: logits = c1 W^T + b
+  {  // classifier[2]: logits = c1 W^T + b  (beside the data gradient of the same layer: both read dlogits, nobody writes it)
+    hipStream_t st_main = st;
+    if (sr.on) sr.sc.fork();
+    hipStream_t st = sr.on ? sr.sc.sd : st_main;
     GemmParams g = gp_linear_geom();
     g.M = d.n_classes; g.N = H; g.K = (int)HM;
     g.A = dlogits; g.a_ld = dl_ld;
@@ -1601,17 +1645,19 @@ static int heads_backward(mmvqa_engine* e, hipStream_t st, const float* h, const
   }
   TRY(lin_dgrad(e, st, dlogits, dl_ld, HM, e->cls2, WS(e->t_b), H, 0, nullptr, 0, nullptr, nullptr, 0));  // dc1
   TRY(ln_bwd(e, st, WS(e->t_b), WS(e->hd_c0), e->cls_ln, WS(e->hd_mean), WS(e->hd_rstd), nullptr, WS(e->t_c), HM));
-  TRY(lin_wgrad(e, st, WS(e->t_c), H, WS(e->hd_u), H, HM, e->cls0, true));
+  TRY(lin_wgrad_side(e, sr, st, WS(e->t_c), H, WS(e->hd_u), H, HM, e->cls0, true));
   TRY(lin_dgrad(e, st, WS(e->t_c), H, HM, e->cls0, WS(e->t_b), H, ACT_SERF, WS(e->hd_upre), H, GRD(e->fc1.b), nullptr, 0));
-  TRY(lin_wgrad(e, st, WS(e->t_b), H, hin, H, HM, e->fc1, false));
+  TRY(lin_wgrad_side(e, sr, st, WS(e->t_b), H, hin, H, HM, e->fc1, false));
   float* dh = WS(e->t_a);
   if (d.head_kind == 1) {
+    sr.write(WS(e->t_c));
     TRY(lin_dgrad(e, st, WS(e->t_b), H, HM, e->fc1, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0));
     RUN(PROF_OTHER, 0, k_meanpool_bwd(st, WS(e->t_c), e->mask, dh, e->B, e->T, H, 0));
   } else {
     TRY(lin_dgrad(e, st, WS(e->t_b), H, HM, e->fc1, dh, H, 0, nullptr, 0, nullptr, nullptr, 0));
   }
   if (d.supcon && dfeat) {
+    sr.write(WS(e->t_b)); sr.write(WS(e->t_c));
     float* df = WS(e->t_b);  // [B][feat_dim]
     RUN(PROF_OTHER, 0, k_l2norm_bwd(st, dfeat, WS(e->sc_y), WS(e->sc_nrm), df, e->B, d.feat_dim));
     TRY(lin_wgrad(e, st, df, d.feat_dim, WS(e->sc_a), H, e->B, e->head2, true));
@@ -1671,10 +1717,18 @@ int engine_backward(mmvqa_engine* e, hipStream_t st, const float* dlogits, int d
   struct TunerScope { TunerScope(IgemmTuner* t) { mmvqa_set_tuner(t); } ~TunerScope() { mmvqa_set_tuner(nullptr); } } ts(&e->tuner);
   e->ev_next = 0;
   const float* h = WS(e->enc_out_final);
-  TRY(heads_backward(e, st, h, dlogits, dl_ld, dfeat));
-  if (d.encoder == 0) TRY(bert_backward(e, st, WS(e->emb_out)));
-  else TRY(rf_backward(e, st, WS(e->emb_out)));
-  if (e->grad_cb) e->grad_cb(e->grad_cb_user, e->enc_lo, e->n_params);   // heads + encoder gradients are final
+  SideCtx sc_enc(e, st);
+  SideReads sr(sc_enc);
+  TRY(heads_backward(e, st, h, dlogits, dl_ld, dfeat, sr));
+  if (d.encoder == 0) TRY(bert_backward(e, st, WS(e->emb_out), sr));
+  else {
+    sr.write(WS(e->t_b)); sr.write(WS(e->t_c));   // (the RealFormer backward runs on the caller's stream only)
+    TRY(rf_backward(e, st, WS(e->emb_out)));
+  }
+  if (e->grad_cb) {
+    sr.join();   // the weight gradients of the range may still be queued on the side stream
+    e->grad_cb(e->grad_cb_user, e->enc_lo, e->n_params);   // heads + encoder gradients are final
+  }
   const float pe = e->training ? d.p_emb_drop : 0.f;
   e->prof_reg = REG_EMBED;
   RUN(PROF_OTHER, 0,
