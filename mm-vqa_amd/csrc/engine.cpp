@@ -1540,7 +1540,7 @@ static int rf_forward(mmvqa_engine* e, hipStream_t st, const float* x_in, const 
   return MMVQA_OK;
 }
 
-static int rf_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
+static int rf_backward(mmvqa_engine* e, hipStream_t st, const float* x_in, SideReads& sr) {
   REG(REG_ENC);
   const mmvqa_model_desc& d = e->d;
   const int H = d.hidden, es = H / 8;
@@ -1551,26 +1551,33 @@ static int rf_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
     RFLayerRef& L = e->rf[i];
     const float* x = i == 0 ? x_in : WS(e->rf[i - 1].x2);
     // x2 = ln2(s2), s2 = x1 + drop(ff2(serf(ff0(x1))))
+    sr.write(WS(e->t_d));
     TRY(ln_bwd(e, st, dx2, WS(L.s2), L.ln2, WS(L.mean2), WS(L.rstd2), nullptr, WS(e->t_d), M));
     float* ds2 = WS(e->t_d);
     const float* dff = ds2;
     if (p > 0.f) {
+      sr.write(WS(e->t_b));
       RUNB(HB_DROPOUT_COPY, 8.0 * M * H, k_dropout_copy(st, ds2, WS(e->t_b), M * H, p, site_seed(e, i, 2)));
       dff = WS(e->t_b);
     }
-    TRY(lin_wgrad(e, st, dff, H, WS(L.hact), 4 * H, M, L.ff2, true));
+    TRY(lin_wgrad_side(e, sr, st, dff, H, WS(L.hact), 4 * H, M, L.ff2, true));
+    sr.write(WS(e->t_big));
     TRY(lin_dgrad(e, st, dff, H, M, L.ff2, WS(e->t_big), 4 * H, ACT_SERF, WS(L.pre), 4 * H, GRD(L.ff0.b), nullptr, 0));
-    TRY(lin_wgrad(e, st, WS(e->t_big), 4 * H, WS(L.x1), H, M, L.ff0, false));
+    TRY(lin_wgrad_side(e, sr, st, WS(e->t_big), 4 * H, WS(L.x1), H, M, L.ff0, false));
+    sr.write(WS(e->t_c));
     TRY(lin_dgrad(e, st, WS(e->t_big), 4 * H, M, L.ff0, WS(e->t_c), H, 0, nullptr, 0, nullptr, ds2, H));  // dx1 total
     // x1 = ln1(s1), s1 = x + drop(proj(res))
+    sr.write(WS(e->t_d));
     TRY(ln_bwd(e, st, WS(e->t_c), WS(L.s1), L.ln1, WS(L.mean1), WS(L.rstd1), nullptr, WS(e->t_d), M));
     float* ds1 = WS(e->t_d);
     const float* dr = ds1;
     if (p > 0.f) {
+      sr.write(WS(e->t_b));
       RUNB(HB_DROPOUT_COPY, 8.0 * M * H, k_dropout_copy(st, ds1, WS(e->t_b), M * H, p, site_seed(e, i, 1)));
       dr = WS(e->t_b);
     }
-    TRY(lin_wgrad(e, st, dr, H, WS(L.res), H, M, L.proj, false));
+    TRY(lin_wgrad_side(e, sr, st, dr, H, WS(L.res), H, M, L.proj, false));
+    sr.write(WS(e->t_c));
     TRY(lin_dgrad(e, st, dr, H, M, L.proj, WS(e->t_c), H, 0, nullptr, 0, nullptr, nullptr, 0));  // dres
     AttnParams a;
     memset(&a, 0, sizeof(a));
@@ -1584,9 +1591,11 @@ static int rf_backward(mmvqa_engine* e, hipStream_t st, const float* x_in) {
     a.dk = dkqv; a.dq = dkqv + es; a.dv = dkqv + 2 * es;
     a.dprev_in = (i < d.n_layers - 1) ? WS(e->t_dprev[(i + 1) & 1]) : nullptr;
     a.dprev_out = i > 0 ? WS(e->t_dprev[i & 1]) : nullptr;
+    sr.write(dkqv);
     TRY(attn_call(e, st, a, es, 1));
     { REG(REG_QKV);
-      TRY(lin_wgrad(e, st, dkqv, 3 * es, x, es, M * 8, L.kqv, false));
+      TRY(lin_wgrad_side(e, sr, st, dkqv, 3 * es, x, es, M * 8, L.kqv, false));
+      sr.write(dx2);
       TRY(lin_dgrad(e, st, dkqv, 3 * es, M * 8, L.kqv, dx2, es, 0, nullptr, 0, nullptr, ds1, es)); }  // dx total
   }
   return MMVQA_OK;
@@ -1721,10 +1730,7 @@ int engine_backward(mmvqa_engine* e, hipStream_t st, const float* dlogits, int d
   SideReads sr(sc_enc);
   TRY(heads_backward(e, st, h, dlogits, dl_ld, dfeat, sr));
   if (d.encoder == 0) TRY(bert_backward(e, st, WS(e->emb_out), sr));
-  else {
-    sr.write(WS(e->t_b)); sr.write(WS(e->t_c));   // (the RealFormer backward runs on the caller's stream only)
-    TRY(rf_backward(e, st, WS(e->emb_out)));
-  }
+  else TRY(rf_backward(e, st, WS(e->emb_out), sr));
   if (e->grad_cb) {
     sr.join();   // the weight gradients of the range may still be queued on the side stream
     e->grad_cb(e->grad_cb_user, e->enc_lo, e->n_params);   // heads + encoder gradients are final
