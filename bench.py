@@ -347,6 +347,7 @@ def main():
         step()
         torch.cuda.synchronize()
         gs = model.profile_read()["igemm"]
+        regs_alone = model.profile_read_regions()
         model.profile(False)
         ach_alone = gs["flops"] / (gs["ms"] * 1e-3) / 1e12 if gs["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
@@ -376,6 +377,10 @@ def main():
                                            "stream join included): unlike `frac` it does not shrink when launches overlap")
         if CONFIG in (2, 3):
             roof["blocks"] = per_block(regs, marks, model, a)
+            # the same table from the one-stream pass: every launch alone on the chip.  In the step the weight gradients run
+            # beside the data gradients (encoder included since round 3), which stretches each launch's own duration and
+            # with it every figure of `blocks`, although the step gets shorter
+            roof["blocks_single_stream"] = per_block(regs_alone, {}, model, a)
         # the HBM-bound kernels one by one: algorithmic bytes (every tensor read / written once, fp32) over the HIP-event
         # time of their launches in this step, against the 8 TB/s roofline
         roof["hbm_kernels"] = {k: dict(launches=v["launches"], ms=v["ms"], algorithmic_gb=v["bytes"] / 1e9,
