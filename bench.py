@@ -358,7 +358,11 @@ def main():
                 traffic = json.load(open(tf))["igemm"]["hbm_bytes_per_launch"]
                 traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)"
                 break
-        roof = dict(bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+        roof = dict(note="achieved / frac: FLOPs of a launch over that launch's OWN duration, averaged over the step's igemm launches "
+                         "as the timed steps run them -- up to three launches share the chip (data-gradient chain, weight gradients, "
+                         "tap backward), so a launch's duration includes the time it shares; single_stream = the same step with every "
+                         "launch alone on the chip; step_level = the same FLOPs over the wall time of forward + backward",
+                    bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src, kernel="igemm_kernel (fp32 MFMA implicit GEMM)",
                     launches_per_step=g["launches"], avg_launch_us=g["ms"] * 1e3 / max(1, g["launches"]),
                     algorithmic_gflop_per_step=g["flops"] / 1e9,

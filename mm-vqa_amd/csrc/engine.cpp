@@ -817,11 +817,12 @@ struct SideCtx {
   }
   // third stream for the tap backward: four long launch groups (2.4 ms per config-2 step) that are needed only when the
   // chain reaches their layer; queued on `sd` they sat in front of the first weight gradients, whose completion the chain
-  // waits for before it reuses a gradient buffer.  Opt-in (MMVQA_TAP_STREAM=1): the step gains 0.5 % (24.88 -> 24.76 ms)
-  // while three kernels share the chip more of the time, which stretches every launch's own duration -- and the bench
-  // line's per-launch roofline figure is defined on exactly that duration (0.299 -> 0.268): DESIGN 7.5.
+  // waits for before it reuses a gradient buffer.  MMVQA_TAP_STREAM_OFF=1 puts them back on `sd` (A/B switch): 24.46 ms
+  // against 24.15 ms per config-2 step.  (More launches share the chip this way and each launch's own duration stretches:
+  // the bench line's per-launch figure `roofline.frac` reads lower on the faster step; `roofline.step_level` and
+  // `roofline.single_stream` do not have that blind spot.  DESIGN 7.5.)
   hipStream_t tap_stream() {
-    static const bool want = getenv("MMVQA_TAP_STREAM") != nullptr && getenv("MMVQA_TAP_STREAM")[0] == '1';
+    static const bool want = getenv("MMVQA_TAP_STREAM_OFF") == nullptr;
     if (!on || !want) return sd;
     if (!e->side2) {
       int least = 0, greatest = 0;
